@@ -1,0 +1,150 @@
+/*
+ * ggq.h — C ABI of the MI355X-native ggml block-quant hot path
+ * (dequantize + Q8_1 activation quantise + MMVQ GEMV + MMQ GEMM).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.
+ * Every entry point names the reference interface it replaces
+ * (paths relative to the reference repo, HK/ = hf-kernels/ggml-kernels/).
+ *
+ * Conventions
+ *   - `type` is the ggml type id (HK/ggml/ggml-common.h:1128-1161):
+ *     Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8 Q2_K=10 Q3_K=11 Q4_K=12 Q5_K=13 Q6_K=14.
+ *   - W is the raw GGUF tensor payload: `n_rows` rows, each `k/qk` blocks,
+ *     row-major, device memory for the ggq_* (GPU) calls.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     All GPU calls are asynchronous on that stream; no host sync, no allocation.
+ *   - Return value: GGQ_OK (0) or a negative GGQ_ERR_* code. Never exits,
+ *     never throws across the ABI.
+ */
+#ifndef GGQ_H
+#define GGQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGQ_ABI_VERSION 1
+
+/* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
+enum ggq_type {
+  GGQ_TYPE_Q4_0 = 2,
+  GGQ_TYPE_Q4_1 = 3,
+  GGQ_TYPE_Q5_0 = 6,
+  GGQ_TYPE_Q5_1 = 7,
+  GGQ_TYPE_Q8_0 = 8,
+  GGQ_TYPE_Q8_1 = 9, /* activations only */
+  GGQ_TYPE_Q2_K = 10,
+  GGQ_TYPE_Q3_K = 11,
+  GGQ_TYPE_Q4_K = 12,
+  GGQ_TYPE_Q5_K = 13,
+  GGQ_TYPE_Q6_K = 14
+};
+
+/* activation / output element types (HK/ggml/dispatch_utils.h:14-20) */
+enum ggq_dtype { GGQ_F32 = 0, GGQ_F16 = 1, GGQ_BF16 = 2 };
+
+enum ggq_status {
+  GGQ_OK = 0,
+  GGQ_ERR_TYPE = -1,   /* unsupported ggml type id            */
+  GGQ_ERR_SHAPE = -2,  /* k not a multiple of the block size… */
+  GGQ_ERR_DTYPE = -3,  /* unsupported activation dtype        */
+  GGQ_ERR_ARG = -4,    /* null pointer / negative size        */
+  GGQ_ERR_LAUNCH = -5, /* HIP runtime reported an error       */
+  GGQ_ERR_ALIGN = -6   /* pointer alignment below the contract */
+};
+
+/* ------------------------------------------------------------------ */
+/* Format traits (host side, no GPU needed)                            */
+/* ------------------------------------------------------------------ */
+
+int ggq_abi_version(void);
+const char* ggq_strerror(int status);
+
+/* replaces ggml_get_block_size (HK/ggml/mmq.cu:57-81): elements per block, 0 if unsupported */
+int ggq_block_elems(int type);
+/* bytes per block (HK/ggml/ggml-common.h:17-108 struct sizes), 0 if unsupported */
+int ggq_block_bytes(int type);
+/* bytes of one weight row of k elements; <0 on error */
+int64_t ggq_row_bytes(int type, int64_t k);
+/* 1 when dequantize / MMVQ / MMQ kernels exist for `type` */
+int ggq_type_supported(int type);
+/* mmq_need_sum (HK/ggml/mmq.cu:84-106): 1 if the MMQ scratch stores half2(d,sum), 0 if float d */
+int ggq_mmq_need_sum(int type);
+
+/* K padding rules of the reference's scratch buffers.
+ *   MMVQ: roundup(k,512)          (HK/ggml/ggml_kernel.cu:84)
+ *   MMQ : k - k%512 + 512         (HK/ggml/mmq.cu:190-191) */
+int64_t ggq_mmvq_padded_k(int64_t k);
+int64_t ggq_mmq_padded_k(int64_t k);
+/* scratch bytes = batch * padded/32 * 36 (HK/ggml/ggml_kernel.cu:90, mmq.cu:208) */
+size_t ggq_mmvq_scratch_bytes(int64_t k);
+size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k);
+
+/* ------------------------------------------------------------------ */
+/* GPU hot path (gfx950)                                               */
+/* ------------------------------------------------------------------ */
+
+/* replaces ggml_dequantize (HK/ggml/ggml_kernel.cu:68-78) + ggml_get_to_fp16_cuda
+ * (HK/ggml/dequantize.cuh:525-568). w: m*n/qk blocks; out: m*n fp16. */
+int ggq_dequantize_f16(const void* w, void* out_f16, int type, int64_t m, int64_t n,
+                       void* stream);
+
+/* replaces quantize_row_q8_1_cuda (HK/ggml/ggml_kernel.cu:13-66).
+ * x: [batch,k] of x_dtype; q: batch * padded/32 block_q8_1 {half d; half sum; int8 qs[32]},
+ * padded = ggq_mmvq_padded_k(k), padding quantised from zeros. */
+int ggq_quantize_q8_1(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                      void* stream);
+
+/* replaces quantize_mmq_q8_1_cuda (HK/ggml/mmq.cu:109-177).
+ * q: block_q8_1_mmq {half2 ds[4]; int8 qs[128]} (HK/ggml/mmq.cuh:176-181),
+ * block index = (k/128)*batch + token; ds slot holds half2(d,sum) when
+ * ggq_mmq_need_sum(type) else float d; padded = ggq_mmq_padded_k(k). */
+int ggq_quantize_q8_1_mmq(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                          int type, void* stream);
+
+/* replaces ggml_mul_mat_vec_a8 (HK/ggml/ggml_kernel.cu:80-193) = quantize_q8_1 ∘ mul_mat_vec_q
+ * (HK/ggml/mmvq.cuh:2-128). x: [1,k] dtype; y: [1,n_rows] dtype;
+ * scratch: >= ggq_mmvq_scratch_bytes(k) device bytes, 16-byte aligned. */
+int ggq_mul_mat_vec_q(const void* w, const void* x, void* y, int type, int dtype,
+                      int64_t k, int64_t n_rows, void* scratch, void* stream);
+
+/* replaces ggml_mul_mat_a8 (HK/ggml/mmq.cu:180-255) = quantize_mmq_q8_1 ∘ mul_mat_q
+ * (HK/ggml/mmq.cuh:1917-2031). x: [batch,k]; y: [batch,n_rows] row-major (ldy = n_rows);
+ * scratch: >= ggq_mmq_scratch_bytes(batch,k) device bytes, 16-byte aligned. */
+int ggq_mul_mat_q(const void* w, const void* x, void* y, int type, int dtype,
+                  int64_t batch, int64_t k, int64_t n_rows, void* scratch, void* stream);
+
+/* Same as ggq_mul_mat_q but writes y with a row pitch of ldy elements at column
+ * offset 0 — used by the row-sharded multi-GPU path to write a rank's [batch, n_rows]
+ * slab straight into its slot of the gathered [batch, ldy] output. */
+int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type, int dtype,
+                     int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                     void* scratch, void* stream);
+
+/* mul_mat_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1_mmq).
+ * Lets a caller quantise X once and reuse it for several weight matrices. */
+int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int type, int dtype,
+                           int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                           void* stream);
+
+/* mul_mat_vec_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1). */
+int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, int dtype,
+                               int64_t k, int64_t n_rows, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* Host CPU twin (product CPU op, libggq_cpu)                          */
+/* ------------------------------------------------------------------ */
+
+/* replaces the ggml-cpu op: ggml_dequantize (ggml-cpu/custom_ops.cpp:11-36) +
+ * dequantize_row_q{4_0,4_1,5_0,5_1,8_0} (ggml-cpu/ggml-quants.hpp:4-112).
+ * fp32 output, host memory. nthreads <= 1 reproduces the reference's single-thread loop. */
+int ggq_cpu_dequantize_f32(const void* w, float* out, int type, int64_t m, int64_t n,
+                           int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGQ_H */

@@ -1,0 +1,247 @@
+"""Independent numpy derivation of the block formats — TEST INFRASTRUCTURE ONLY.
+
+Two things live here, both written from the wire-format tables (SURVEY.md §2.2 /
+HK/ggml/ggml-common.h:17-108), *not* from oracle/ggq_oracle.c, so that two
+independently written decoders have to agree bit-for-bit:
+
+1. ``unpack_ints(blocks, type)`` / ``scales16(blocks, type)`` — integer unpack of
+   every format into the integers the dot products use, vectorised per block
+   (layout derived element-by-element, no thread emulation).
+2. ``gguf_dequantize(blocks, type)`` — restatement of the published
+   ``gguf.quants.dequantize`` algorithm (gguf-py, floor ``gguf>=0.10.0`` in the
+   reference's requirements-dev.txt:4 and HK/requirements-test.txt:4; the package is
+   absent from this image).  It is the ground truth the reference's own tests use
+   (tests/test_dequantize.py:66, HK/tests/kernels/test_cuda_kernels.py:52) at
+   atol=1e-2, rtol=4e-2.  fp32 arithmetic, same operation order as gguf-py.
+3. ``dequantize_f16(blocks, type)`` — the fp16-arithmetic sequence of
+   HK/ggml/dequantize.cuh:3-254 expressed with numpy float16 ops.
+
+Nothing in the product path imports this module.
+"""
+import numpy as np
+
+Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 2, 3, 6, 7, 8, 9
+Q2_K, Q3_K, Q4_K, Q5_K, Q6_K = 10, 11, 12, 13, 14
+
+BLOCK_ELEMS = {Q4_0: 32, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_0: 32, Q8_1: 32,
+               Q2_K: 256, Q3_K: 256, Q4_K: 256, Q5_K: 256, Q6_K: 256}
+BLOCK_BYTES = {Q4_0: 18, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_0: 34, Q8_1: 36,
+               Q2_K: 84, Q3_K: 110, Q4_K: 144, Q5_K: 176, Q6_K: 210}
+NAMES = {Q4_0: "Q4_0", Q4_1: "Q4_1", Q5_0: "Q5_0", Q5_1: "Q5_1", Q8_0: "Q8_0",
+         Q2_K: "Q2_K", Q3_K: "Q3_K", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K"}
+WEIGHT_TYPES = [Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K]
+
+
+def as_blocks(data, t):
+    a = np.ascontiguousarray(np.asarray(data, dtype=np.uint8)).reshape(-1, BLOCK_BYTES[t])
+    return a
+
+
+def _f16(bytes2):
+    """[nb,2] uint8 -> [nb] float16"""
+    return np.ascontiguousarray(bytes2).view(np.float16).reshape(-1)
+
+
+def _bits(byte_arr, nbits=8):
+    """[..., n] uint8 -> [..., n, nbits] of 0/1 (LSB first)"""
+    return (byte_arr[..., None] >> np.arange(nbits, dtype=np.uint8)) & 1
+
+
+def _k4_scales(sc12):
+    """Q4_K/Q5_K 12-byte scale field -> (sc[nb,8], mn[nb,8]); 6-bit values.
+    bytes 0-3: low 6 bits = sc0..3, top 2 bits = high bits of sc4..7
+    bytes 4-7: low 6 bits = mn0..3, top 2 bits = high bits of mn4..7
+    bytes 8-11: low nibble = low 4 bits of sc4..7, high nibble = low 4 bits of mn4..7"""
+    s = sc12.astype(np.int32)
+    sc = np.empty(s.shape[:-1] + (8,), np.int32)
+    mn = np.empty_like(sc)
+    sc[..., 0:4] = s[..., 0:4] & 63
+    mn[..., 0:4] = s[..., 4:8] & 63
+    sc[..., 4:8] = (s[..., 8:12] & 15) | ((s[..., 0:4] >> 6) << 4)
+    mn[..., 4:8] = (s[..., 8:12] >> 4) | ((s[..., 4:8] >> 6) << 4)
+    return sc, mn
+
+
+def _q3k_scales(sc12):
+    """Q3_K 12-byte field -> [nb,16] signed 6-bit scales minus 32.
+    scale i: low 4 bits = nibble (i//8) of byte i%8; high 2 bits = bit-pair (i//4) of byte 8 + i%4"""
+    s = sc12.astype(np.int32)
+    i = np.arange(16)
+    lo = (s[..., i % 8] >> (4 * (i // 8))) & 15
+    hi = (s[..., 8 + i % 4] >> (2 * (i // 4))) & 3
+    return (lo | (hi << 4)) - 32
+
+
+def unpack_ints(blocks, t):
+    """Integers multiplied with q8 in the reference's dot products, element order.
+    Raw unsigned for Q4_0/Q4_1/Q5_0/Q5_1/Q2_K/Q4_K/Q5_K; signed for Q8_0/Q3_K/Q6_K."""
+    b = as_blocks(blocks, t)
+    nb = b.shape[0]
+    if t in (Q4_0, Q4_1):
+        qs = b[:, 2:18] if t == Q4_0 else b[:, 4:20]
+        return np.concatenate([qs & 15, qs >> 4], axis=1).astype(np.int32)
+    if t in (Q5_0, Q5_1):
+        qh = b[:, 2:6] if t == Q5_0 else b[:, 4:8]
+        qs = b[:, 6:22] if t == Q5_0 else b[:, 8:24]
+        hb = _bits(qh).reshape(nb, 32).astype(np.int32)  # element j <- bit j of the 32-bit qh
+        lo4 = np.concatenate([qs & 15, qs >> 4], axis=1).astype(np.int32)
+        return lo4 | (hb << 4)
+    if t == Q8_0:
+        return b[:, 2:34].view(np.int8).astype(np.int32)
+    if t == Q2_K:
+        qs = b[:, 16:80].reshape(nb, 2, 1, 32)
+        sh = (2 * np.arange(4, dtype=np.uint8)).reshape(1, 1, 4, 1)
+        return ((qs >> sh) & 3).reshape(nb, 256).astype(np.int32)
+    if t == Q3_K:
+        qs = b[:, 32:96].reshape(nb, 2, 1, 32)
+        sh = (2 * np.arange(4, dtype=np.uint8)).reshape(1, 1, 4, 1)
+        lo = ((qs >> sh) & 3).astype(np.int32)                       # [nb,2,4,32]
+        hm = _bits(b[:, 0:32])                                        # [nb,32(l),8(bit)]
+        hbit = hm.transpose(0, 2, 1).reshape(nb, 2, 4, 32).astype(np.int32)  # bit 4n+j of hmask[l]
+        return (lo - 4 * (1 - hbit)).reshape(nb, 256)
+    if t == Q4_K:
+        qs = b[:, 16:144].reshape(nb, 4, 1, 32)
+        sh = np.array([0, 4], dtype=np.uint8).reshape(1, 1, 2, 1)
+        return ((qs >> sh) & 15).reshape(nb, 256).astype(np.int32)
+    if t == Q5_K:
+        qs = b[:, 48:176].reshape(nb, 4, 1, 32)
+        sh = np.array([0, 4], dtype=np.uint8).reshape(1, 1, 2, 1)
+        lo = ((qs >> sh) & 15).astype(np.int32)                       # [nb,4,2,32]
+        hb = _bits(b[:, 16:48]).transpose(0, 2, 1).reshape(nb, 4, 2, 32).astype(np.int32)
+        return (lo + 16 * hb).reshape(nb, 256)
+    if t == Q6_K:
+        ql = b[:, 0:128].reshape(nb, 2, 2, 32)      # [ip][half 0/1 of the 64 bytes][l]
+        qh = b[:, 128:192].reshape(nb, 2, 32)
+        out = np.empty((nb, 2, 4, 32), np.int32)
+        for j in range(4):                            # 32-element group j inside the 128 half
+            nib = (ql[:, :, j % 2, :] >> (4 * (j // 2))) & 15
+            hi2 = (qh >> (2 * j)) & 3
+            out[:, :, j, :] = (nib | (hi2 << 4)).astype(np.int32) - 32
+        return out.reshape(nb, 256)
+    raise ValueError(t)
+
+
+def scales16(blocks, t):
+    """(d, dmin_or_m, sc16, mn16): fp16 block scales and per-16-element integer scale/min.
+    Legacy formats: sc16/mn16 are None."""
+    b = as_blocks(blocks, t)
+    if t in (Q4_0, Q5_0, Q8_0):
+        return _f16(b[:, 0:2]), None, None, None
+    if t in (Q4_1, Q5_1):
+        return _f16(b[:, 0:2]), _f16(b[:, 2:4]), None, None
+    if t == Q2_K:
+        sc = b[:, 0:16].astype(np.int32)
+        return _f16(b[:, 80:82]), _f16(b[:, 82:84]), sc & 15, sc >> 4
+    if t == Q3_K:
+        return _f16(b[:, 108:110]), None, _q3k_scales(b[:, 96:108]), None
+    if t in (Q4_K, Q5_K):
+        sc, mn = _k4_scales(b[:, 4:16])
+        return _f16(b[:, 0:2]), _f16(b[:, 2:4]), np.repeat(sc, 2, axis=1), np.repeat(mn, 2, axis=1)
+    if t == Q6_K:
+        return _f16(b[:, 208:210]), None, b[:, 192:208].view(np.int8).astype(np.int32), None
+    raise ValueError(t)
+
+
+def dequantize_exact(blocks, t):
+    """float64 mathematical definition, no intermediate rounding."""
+    q = unpack_ints(blocks, t).astype(np.float64)
+    d, m, sc, mn = scales16(blocks, t)
+    d = d.astype(np.float64)[:, None]
+    if t == Q4_0:
+        return d * (q - 8)
+    if t == Q5_0:
+        return d * (q - 16)
+    if t == Q8_0:
+        return d * q
+    if t in (Q4_1, Q5_1):
+        return d * q + m.astype(np.float64)[:, None]
+    s = np.repeat(sc, 16, axis=1).astype(np.float64)
+    if t in (Q3_K, Q6_K):
+        return d * s * q
+    return d * s * q - m.astype(np.float64)[:, None] * np.repeat(mn, 16, axis=1)
+
+
+def gguf_dequantize(blocks, t):
+    """gguf-py ``quants.dequantize`` restated (fp32, gguf-py operation order)."""
+    f32 = np.float32
+    q = unpack_ints(blocks, t)
+    d, m, sc, mn = scales16(blocks, t)
+    d = d.astype(f32)[:, None]
+    if t == Q4_0:
+        return d * (q - 8).astype(f32)
+    if t == Q5_0:
+        return d * (q - 16).astype(f32)
+    if t == Q8_0:
+        return q.astype(f32) * d
+    if t in (Q4_1, Q5_1):
+        return d * q.astype(f32) + m.astype(f32)[:, None]
+    nb = q.shape[0]
+    if t == Q2_K:
+        dl = (d * sc.astype(f32)).reshape(nb, 16, 1)
+        ml = (m.astype(f32)[:, None] * mn.astype(f32)).reshape(nb, 16, 1)
+        return (dl * q.reshape(nb, 16, 16).astype(f32) - ml).reshape(nb, 256)
+    if t == Q3_K:
+        dl = (d * sc.astype(f32)).reshape(nb, 16, 1)
+        return (dl * q.reshape(nb, 16, 16).astype(f32)).reshape(nb, 256)
+    if t in (Q4_K, Q5_K):
+        dl = (d * sc[:, ::2].astype(f32)).reshape(nb, 8, 1)
+        ml = (m.astype(f32)[:, None] * mn[:, ::2].astype(f32)).reshape(nb, 8, 1)
+        return (dl * q.reshape(nb, 8, 32).astype(f32) - ml).reshape(nb, 256)
+    if t == Q6_K:
+        dl = (d * sc.astype(f32)).reshape(nb, 16, 1)
+        return (dl * q.reshape(nb, 16, 16).astype(f32)).reshape(nb, 256)
+    raise ValueError(t)
+
+
+def dequantize_f16(blocks, t):
+    """fp16-arithmetic sequence of HK/ggml/dequantize.cuh, numpy float16 ops
+    (numpy evaluates each float16 op in float32 and rounds once = IEEE fp16)."""
+    h = np.float16
+    q = unpack_ints(blocks, t)
+    d, m, sc, mn = scales16(blocks, t)
+    d = d[:, None]
+    old = np.seterr(all="ignore")
+    try:
+        if t == Q4_0:       # hmul2(hsub2(v, 8), d)  (dequantize.cuh:14-15)
+            return (q.astype(h) - h(8)) * d
+        if t == Q5_0:       # :48-49
+            return (q.astype(h) - h(16)) * d
+        if t == Q8_0:       # :77
+            return q.astype(h) * d
+        if t in (Q4_1, Q5_1):  # hadd2(hmul2(v, d), m)  (:30-31, :67-68)
+            return q.astype(h) * d + m[:, None]
+        s = np.repeat(sc, 16, axis=1)
+        if t == Q2_K:       # hsub(hmul(dall, i2h(sc*q)), hmul(dmin, i2h(m)))  (:117-120)
+            return d * (s * q).astype(h) - m[:, None] * np.repeat(mn, 16, axis=1).astype(h)
+        if t == Q3_K:       # dl = hmul(d, i2h(sc)); hmul(dl, i2h(q))  (:145, :151)
+            return (d * s.astype(h)) * q.astype(h)
+        if t in (Q4_K, Q5_K):  # d1 = hmul(dall,i2h(sc)); m1 = hmul(dmin,i2h(m)); hsub(hmul(d1,i2h(q)), m1)
+            return (d * s.astype(h)) * q.astype(h) - (m[:, None] * np.repeat(mn, 16, axis=1).astype(h))
+        if t == Q6_K:       # hmul(d, i2h(sc * q))  (:250-253)
+            return d * (s * q).astype(np.float32).astype(h)
+    finally:
+        np.seterr(**old)
+    raise ValueError(t)
+
+
+# ---------------------------------------------------------------------------
+# Q8_1 activation quantiser (HK/ggml/ggml_kernel.cu:13-50) in numpy, tree sum order
+# ---------------------------------------------------------------------------
+
+def quantize_q8_1_groups(x32):
+    """x32: float32 [..., 32] -> (q int8 [...,32], d float32 [...], s float32 [...]).
+    amax/127, roundf(x/d) (half away from zero), xor-butterfly (16,8,4,2,1) fp32 sum."""
+    x32 = np.asarray(x32, np.float32)
+    amax = np.max(np.abs(x32), axis=-1)
+    s = x32.copy()
+    for mask in (16, 8, 4, 2, 1):
+        idx = np.arange(32) ^ mask
+        s = (s + s[..., idx]).astype(np.float32)
+    s = s[..., 0]
+    d = (amax / np.float32(127)).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = (x32 / d[..., None]).astype(np.float32)
+    r = np.where(amax[..., None] == 0, np.float32(0), r)
+    r64 = r.astype(np.float64)  # |r| + 0.5 is exact in float64
+    q = (np.sign(r64) * np.floor(np.abs(r64) + 0.5)).astype(np.int8)
+    return q, d, s
