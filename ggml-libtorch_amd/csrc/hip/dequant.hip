@@ -1,0 +1,237 @@
+// dequant.hip — block-quantised weights -> fp16, gfx950.
+//
+// Replaces HK/ggml/dequantize.cuh:3-254 (kernels) + :435-568 (launch/dispatch) and
+// ggml_dequantize (HK/ggml/ggml_kernel.cu:68-78) of the reference.
+//
+// Result contract: bit-identical to the reference kernels, i.e. every __hmul/__hsub/
+// __hadd/__int2half_rn of dequantize.cuh is one IEEE fp16 operation here too
+// (-ffp-contract=off; the compiler would otherwise fuse hsub(hmul()) into v_fma_f16).
+//
+// Design (HBM-bound: 0.56-1.06 B/elem in, 2 B/elem out):
+//   * one thread = 8 consecutive output elements = one 16-byte store; a wave stores
+//     1 KiB contiguous per instruction, so the 78 % of traffic that is writes is
+//     perfectly coalesced;
+//   * the 8 source bytes of a thread are contiguous in every format, so each thread
+//     issues one 8-byte quant load (+ one 4-16 byte scale/header load that is shared
+//     by the 4-32 neighbouring lanes of the same block and served by one L1 line);
+//     a wave's loads cover a contiguous byte range of the weight row;
+//   * no LDS: nothing is reused across lanes except the block header.
+#include "ggq_common.h"
+
+namespace ggq {
+
+__device__ __forceinline__ _Float16 i2h(int v) { return (_Float16)v; }  // __int2half_rn
+
+// ---- per-format decode of the 8-element chunk `sub` of one block -----------
+template <int T> struct Decode;
+
+// Q4_0 / Q4_1 / Q5_0 / Q5_1: element e<16 -> low nibble of qs[e], e>=16 -> high nibble of qs[e-16]
+template <> struct Decode<GGQ_TYPE_Q4_0> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const _Float16 d = bits_h(ld_u16(b + off::Q4_0_D));
+    const u32x2_a2 q = ld_u32x2(b + off::Q4_0_QS + 8 * (sub & 1));
+    const int sh = 4 * (sub >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = (q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF;
+      y[i] = (i2h(n) - (_Float16)8.0f) * d;  // dequantize.cuh:11-15
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_Q4_1> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const uint32_t dm = ld_u32(b + off::Q4_1_D);
+    const _Float16 d = bits_h(dm & 0xFFFF), m = bits_h(dm >> 16);
+    const u32x2_a2 q = ld_u32x2(b + off::Q4_1_QS + 8 * (sub & 1));
+    const int sh = 4 * (sub >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = (q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF;
+      y[i] = i2h(n) * d + m;  // dequantize.cuh:27-31
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_Q5_0> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const _Float16 d = bits_h(ld_u16(b + off::Q5_0_D));
+    const uint32_t qh = ld_u32(b + off::Q5_0_QH) >> (8 * sub);  // element e <- bit e
+    const u32x2_a2 q = ld_u32x2(b + off::Q5_0_QS + 8 * (sub & 1));
+    const int sh = 4 * (sub >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = ((q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF) | (((qh >> i) & 1) << 4);
+      y[i] = (i2h(n) - (_Float16)16.0f) * d;  // dequantize.cuh:45-49
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_Q5_1> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const uint32_t dm = ld_u32(b + off::Q5_1_D);
+    const _Float16 d = bits_h(dm & 0xFFFF), m = bits_h(dm >> 16);
+    const uint32_t qh = ld_u32(b + off::Q5_1_QH) >> (8 * sub);
+    const u32x2_a2 q = ld_u32x2(b + off::Q5_1_QS + 8 * (sub & 1));
+    const int sh = 4 * (sub >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = ((q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF) | (((qh >> i) & 1) << 4);
+      y[i] = i2h(n) * d + m;  // dequantize.cuh:64-68
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_Q8_0> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const _Float16 d = bits_h(ld_u16(b + off::Q8_0_D));
+    const u32x2_a2 q = ld_u32x2(b + off::Q8_0_QS + 8 * sub);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = (int8_t)(q.v[i >> 2] >> (8 * (i & 3)));
+      y[i] = i2h(n) * d;  // dequantize.cuh:74-77
+    }
+  }
+};
+
+// K-quants. Chunk `sub` (0..31) holds elements 8*sub..8*sub+7 of the super-block.
+// Q2_K/Q3_K: element 128n + 32j + l <- (qs[32n+l] >> 2j) & 3      (dequantize.cuh:105-120)
+template <> struct Decode<GGQ_TYPE_Q2_K> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int n = sub >> 4, j = (sub >> 2) & 3, l0 = 8 * (sub & 3);
+    const uint32_t dm = ld_u32(b + off::Q2_K_D);
+    const _Float16 dall = bits_h(dm & 0xFFFF), dmin = bits_h(dm >> 16);
+    const int sc = b[off::Q2_K_SC + (sub >> 1)];  // scale of the 16-element group e/16
+    const u32x2_a2 q = ld_u32x2(b + off::Q2_K_QS + 32 * n + l0);
+    const _Float16 mterm = dmin * i2h(sc >> 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = (q.v[i >> 2] >> (8 * (i & 3) + 2 * j)) & 3;
+      y[i] = dall * i2h((sc & 0xF) * v) - mterm;  // dequantize.cuh:117-120
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_Q3_K> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int n = sub >> 4, j = (sub >> 2) & 3, l0 = 8 * (sub & 3);
+    const _Float16 d_all = bits_h(ld_u16(b + off::Q3_K_D));
+    const u32x3_a2 s = ld_u32x3(b + off::Q3_K_SC);
+    const int us = q3k_scale(s.v[0], s.v[1], s.v[2], sub >> 1);
+    const _Float16 dl = d_all * i2h(us);  // dequantize.cuh:144-145 (us already minus 32)
+    const u32x2_a2 q = ld_u32x2(b + off::Q3_K_QS + 32 * n + l0);
+    const u32x2_a2 hm = ld_u32x2(b + off::Q3_K_HM + l0);
+    const int hbit = 4 * n + j;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = (q.v[i >> 2] >> (8 * (i & 3) + 2 * j)) & 3;
+      const int hset = (hm.v[i >> 2] >> (8 * (i & 3) + hbit)) & 1;
+      y[i] = dl * i2h(v - (hset ? 0 : 4));  // dequantize.cuh:151
+    }
+  }
+};
+// Q4_K/Q5_K: element 64il + 32h + l <- nibble h of qs[32il + l]   (dequantize.cuh:176-193)
+template <> struct Decode<GGQ_TYPE_Q4_K> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int il = sub >> 3, hsel = (sub >> 2) & 1, l0 = 8 * (sub & 3);
+    const u32x4_a2 hd = ld_u32x4(b);  // dm + 12 scale bytes
+    const _Float16 dall = bits_h(hd.v[0] & 0xFFFF), dmin = bits_h(hd.v[0] >> 16);
+    int sc, mn;
+    k4_scale_min(hd.v[1], hd.v[2], hd.v[3], sub >> 2, sc, mn);
+    const _Float16 d1 = dall * i2h(sc), m1 = dmin * i2h(mn);
+    const u32x2_a2 q = ld_u32x2(b + off::Q4_K_QS + 32 * il + l0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = (q.v[i >> 2] >> (8 * (i & 3) + 4 * hsel)) & 0xF;
+      y[i] = d1 * i2h(v) - m1;  // dequantize.cuh:190-191
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_Q5_K> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int il = sub >> 3, hsel = (sub >> 2) & 1, l0 = 8 * (sub & 3);
+    const u32x4_a2 hd = ld_u32x4(b);
+    const _Float16 dall = bits_h(hd.v[0] & 0xFFFF), dmin = bits_h(hd.v[0] >> 16);
+    int sc, mn;
+    k4_scale_min(hd.v[1], hd.v[2], hd.v[3], sub >> 2, sc, mn);
+    const _Float16 d1 = dall * i2h(sc), m1 = dmin * i2h(mn);
+    const u32x2_a2 q = ld_u32x2(b + off::Q5_K_QS + 32 * il + l0);
+    const u32x2_a2 qh = ld_u32x2(b + off::Q5_K_QH + l0);
+    const int hbit = sub >> 2;  // bit 2il + h of qh[l]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = ((q.v[i >> 2] >> (8 * (i & 3) + 4 * hsel)) & 0xF) +
+                    (((qh.v[i >> 2] >> (8 * (i & 3) + hbit)) & 1) << 4);
+      y[i] = d1 * i2h(v) - m1;  // dequantize.cuh:222-227
+    }
+  }
+};
+// Q6_K: element 128ip + 32j + l <- nibble (j/2) of ql[64ip + 32(j%2) + l] | bits 2j..2j+1 of qh[32ip+l] << 4
+template <> struct Decode<GGQ_TYPE_Q6_K> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int ip = sub >> 4, j = (sub >> 2) & 3, l0 = 8 * (sub & 3);
+    const _Float16 d = bits_h(ld_u16(b + off::Q6_K_D));
+    const int sc = (int8_t)b[off::Q6_K_SC + (sub >> 1)];
+    const u32x2_a2 ql = ld_u32x2(b + off::Q6_K_QL + 64 * ip + 32 * (j & 1) + l0);
+    const u32x2_a2 qh = ld_u32x2(b + off::Q6_K_QH + 32 * ip + l0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int lo = (ql.v[i >> 2] >> (8 * (i & 3) + 4 * (j >> 1))) & 0xF;
+      const int hi = (qh.v[i >> 2] >> (8 * (i & 3) + 2 * j)) & 3;
+      y[i] = d * i2h(sc * ((lo | (hi << 4)) - 32));  // dequantize.cuh:250-253
+    }
+  }
+};
+
+template <int T>
+__global__ void __launch_bounds__(256) dequant_kernel(const uint8_t* __restrict__ w,
+                                                      _Float16* __restrict__ out,
+                                                      int64_t n_chunks) {
+  constexpr int CPB = Fmt<T>::QK / 8;  // 8-element chunks per block
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const int64_t ib = c / CPB;
+  const int sub = (int)(c - ib * CPB);
+  _Float16 y[8];
+  Decode<T>::run(w + ib * Fmt<T>::BS, sub, y);
+  h8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = y[i];
+  *(h8*)(out + c * 8) = v;
+}
+
+template <int T>
+static int launch_dequant(const void* w, void* out, int64_t k, hipStream_t s) {
+  const int64_t n_chunks = k / 8;
+  if (n_chunks == 0) return GGQ_OK;
+  const int64_t grid = (n_chunks + 255) / 256;
+  if (grid > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  hipLaunchKernelGGL(dequant_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s,
+                     (const uint8_t*)w, (_Float16*)out, n_chunks);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
+}
+
+}  // namespace ggq
+
+extern "C" int ggq_dequantize_f16(const void* w, void* out, int type, int64_t m, int64_t n,
+                                  void* stream) {
+  using namespace ggq;
+  if (m < 0 || n < 0) return GGQ_ERR_ARG;
+  const int qk = ggq_block_elems(type);
+  if (qk == 0 || type == GGQ_TYPE_Q8_1) return GGQ_ERR_TYPE;
+  const int64_t k = m * n;
+  if (k % qk) return GGQ_ERR_SHAPE;
+  if (k == 0) return GGQ_OK;
+  if (!w || !out) return GGQ_ERR_ARG;
+  if (((uintptr_t)out & 15) || ((uintptr_t)w & 1)) return GGQ_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  switch (type) {
+    case GGQ_TYPE_Q4_0: return launch_dequant<GGQ_TYPE_Q4_0>(w, out, k, s);
+    case GGQ_TYPE_Q4_1: return launch_dequant<GGQ_TYPE_Q4_1>(w, out, k, s);
+    case GGQ_TYPE_Q5_0: return launch_dequant<GGQ_TYPE_Q5_0>(w, out, k, s);
+    case GGQ_TYPE_Q5_1: return launch_dequant<GGQ_TYPE_Q5_1>(w, out, k, s);
+    case GGQ_TYPE_Q8_0: return launch_dequant<GGQ_TYPE_Q8_0>(w, out, k, s);
+    case GGQ_TYPE_Q2_K: return launch_dequant<GGQ_TYPE_Q2_K>(w, out, k, s);
+    case GGQ_TYPE_Q3_K: return launch_dequant<GGQ_TYPE_Q3_K>(w, out, k, s);
+    case GGQ_TYPE_Q4_K: return launch_dequant<GGQ_TYPE_Q4_K>(w, out, k, s);
+    case GGQ_TYPE_Q5_K: return launch_dequant<GGQ_TYPE_Q5_K>(w, out, k, s);
+    case GGQ_TYPE_Q6_K: return launch_dequant<GGQ_TYPE_Q6_K>(w, out, k, s);
+    default: return GGQ_ERR_TYPE;
+  }
+}

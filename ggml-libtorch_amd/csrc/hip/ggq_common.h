@@ -1,0 +1,144 @@
+// ggq_common.h — shared device helpers for the gfx950 ggml block-quant kernels.
+//
+// Block wire formats follow HK/ggml/ggml-common.h:17-108 of the reference
+// (byte offsets restated below); everything else here is ours.
+// Compile with -ffp-contract=off: the fp16 dequantise sequences must round after
+// every operation exactly like the reference's __hmul/__hsub/__hadd intrinsics.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../../include/ggq.h"
+
+namespace ggq {
+
+constexpr int WAVE = 64;
+
+// ---- vector types ---------------------------------------------------------
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- unaligned loads (gfx950 global/LDS accesses need no natural alignment;
+//      the packed structs tell the compiler only 1/2-byte alignment is known) ----
+struct __attribute__((packed, aligned(2))) u16x1_a2 { uint16_t v; };
+struct __attribute__((packed, aligned(2))) u32x1_a2 { uint32_t v; };
+struct __attribute__((packed, aligned(2))) u32x2_a2 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(2))) u32x3_a2 { uint32_t v[3]; };
+struct __attribute__((packed, aligned(2))) u32x4_a2 { uint32_t v[4]; };
+
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return ((const u16x1_a2*)p)->v; }
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return ((const u32x1_a2*)p)->v; }
+__device__ __forceinline__ u32x2_a2 ld_u32x2(const uint8_t* p) { return *(const u32x2_a2*)p; }
+__device__ __forceinline__ u32x3_a2 ld_u32x3(const uint8_t* p) { return *(const u32x3_a2*)p; }
+__device__ __forceinline__ u32x4_a2 ld_u32x4(const uint8_t* p) { return *(const u32x4_a2*)p; }
+
+__device__ __forceinline__ _Float16 bits_h(uint32_t b) {
+  uint16_t s = (uint16_t)b;
+  return __builtin_bit_cast(_Float16, s);
+}
+__device__ __forceinline__ float bits_h_f32(uint32_t b) { return (float)bits_h(b); }
+
+// ---- block geometry ------------------------------------------------------
+template <int T> struct Fmt;
+#define GGQ_FMT(T, QK_, BS_) \
+  template <> struct Fmt<T> { static constexpr int QK = QK_; static constexpr int BS = BS_; };
+GGQ_FMT(GGQ_TYPE_Q4_0, 32, 18)
+GGQ_FMT(GGQ_TYPE_Q4_1, 32, 20)
+GGQ_FMT(GGQ_TYPE_Q5_0, 32, 22)
+GGQ_FMT(GGQ_TYPE_Q5_1, 32, 24)
+GGQ_FMT(GGQ_TYPE_Q8_0, 32, 34)
+GGQ_FMT(GGQ_TYPE_Q2_K, 256, 84)
+GGQ_FMT(GGQ_TYPE_Q3_K, 256, 110)
+GGQ_FMT(GGQ_TYPE_Q4_K, 256, 144)
+GGQ_FMT(GGQ_TYPE_Q5_K, 256, 176)
+GGQ_FMT(GGQ_TYPE_Q6_K, 256, 210)
+#undef GGQ_FMT
+
+// byte offsets inside a block (HK/ggml/ggml-common.h:20-108)
+namespace off {
+constexpr int Q4_0_D = 0, Q4_0_QS = 2;
+constexpr int Q4_1_D = 0, Q4_1_M = 2, Q4_1_QS = 4;
+constexpr int Q5_0_D = 0, Q5_0_QH = 2, Q5_0_QS = 6;
+constexpr int Q5_1_D = 0, Q5_1_M = 2, Q5_1_QH = 4, Q5_1_QS = 8;
+constexpr int Q8_0_D = 0, Q8_0_QS = 2;
+constexpr int Q2_K_SC = 0, Q2_K_QS = 16, Q2_K_D = 80, Q2_K_DMIN = 82;
+constexpr int Q3_K_HM = 0, Q3_K_QS = 32, Q3_K_SC = 96, Q3_K_D = 108;
+constexpr int Q4_K_D = 0, Q4_K_DMIN = 2, Q4_K_SC = 4, Q4_K_QS = 16;
+constexpr int Q5_K_D = 0, Q5_K_DMIN = 2, Q5_K_SC = 4, Q5_K_QH = 16, Q5_K_QS = 48;
+constexpr int Q6_K_QL = 0, Q6_K_QH = 128, Q6_K_SC = 192, Q6_K_D = 208;
+}  // namespace off
+
+// 6-bit (scale, min) pair j of the 12-byte Q4_K/Q5_K scale field, from the three
+// little-endian dwords s0,s1,s2 of that field (layout: HK/ggml/dequantize.cuh:154-161).
+__device__ __forceinline__ void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t s2, int j,
+                                             int& sc, int& mn) {
+  if (j < 4) {
+    sc = (s0 >> (8 * j)) & 63;
+    mn = (s1 >> (8 * j)) & 63;
+  } else {
+    const int jj = j - 4;
+    const uint32_t b = (s2 >> (8 * jj)) & 0xFF;
+    sc = (b & 0xF) | (((s0 >> (8 * jj + 6)) & 3) << 4);
+    mn = (b >> 4) | (((s1 >> (8 * jj + 6)) & 3) << 4);
+  }
+}
+
+// Q3_K 6-bit scale i (0..15) minus 32, from the dwords of the 12-byte field
+// (low nibble (i/8) of byte i%8, bit pair (i/4) of byte 8+i%4: HK/ggml/dequantize.cuh:140-143).
+__device__ __forceinline__ int q3k_scale(uint32_t s0, uint32_t s1, uint32_t s2, int i) {
+  const int bl = i & 7;
+  const uint32_t wl = bl < 4 ? s0 : s1;
+  const int lo = (wl >> (8 * (bl & 3) + 4 * (i >> 3))) & 0xF;
+  const int hi = (s2 >> (8 * (i & 3) + 2 * (i >> 2))) & 3;
+  return (lo | (hi << 4)) - 32;
+}
+
+// ---- conversions ----------------------------------------------------------
+template <int DT> struct Elem;
+template <> struct Elem<GGQ_F32> {
+  typedef float type;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct Elem<GGQ_F16> {
+  typedef _Float16 type;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) { return (float)((const _Float16*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((_Float16*)p)[i] = (_Float16)v; }
+};
+template <> struct Elem<GGQ_BF16> {
+  typedef uint16_t type;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) {
+    return __builtin_bit_cast(float, ((uint32_t)((const uint16_t*)p)[i]) << 16);
+  }
+  static __device__ __forceinline__ uint16_t cvt(float v) {  // RNE, NaN stays NaN
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = cvt(v); }
+};
+
+// wave-wide sum (all lanes receive the total); order is ours, the parity budget for
+// the fp accumulate is 1e-3 relative (the oracle sums the same terms in a tree).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+#define GGQ_HIP_CHECK_LAUNCH()                          \
+  do {                                                  \
+    hipError_t e_ = hipGetLastError();                  \
+    if (e_ != hipSuccess) return GGQ_ERR_LAUNCH;        \
+  } while (0)
+
+}  // namespace ggq

@@ -1,0 +1,392 @@
+// mmvq.hip — quantised GEMV  y[1,N] = W[N,K] (block-quant) · x[1,K] (Q8_1), gfx950.
+//
+// Replaces mul_mat_vec_q + the per-format launchers (HK/ggml/mmvq.cuh:2-128), the
+// vec_dot_<fmt>_q8_1 library (HK/ggml/vecdotq.cuh:43-605) and the op body of
+// ggml_mul_mat_vec_a8 (HK/ggml/ggml_kernel.cu:80-193).
+//
+// Numerical contract ("MMVQ canon"): the integer dot products are exact;
+// each unit's float combination uses the formula of the matching vec_dot_*_q8_1_impl
+// (incl. the fp16 products of Q4_1/Q5_1 and d8*Σq8 for the Q4_K/Q5_K/Q2_K min term);
+// only the fp32 summation order over the row differs from the reference.
+//
+// Design (HBM-bound: the weight row is read exactly once, nothing else matters):
+//   * weights go global -> VGPR with 16-byte loads, no LDS (each byte is used by one lane);
+//     a lane owns one 16-byte quant slice ("unit") per step, consecutive lanes own
+//     consecutive slices, so a wave's loads sweep a contiguous span of the row;
+//   * the Q8_1 activation row (K bytes + scales) is staged once per workgroup in LDS,
+//     de-interleaved into a contiguous int8 array (16-byte aligned ds_read_b128),
+//     float d / s arrays and per-16 integer sums (min / offset terms);
+//   * one wave per row group, ROWS rows in flight per wave for memory-level parallelism,
+//     64-lane shuffle reduction at the end of each row.
+#include "ggq_common.h"
+
+namespace ggq {
+
+struct ActLds {
+  const int8_t* xq;    // [K]     int8 activations, element order
+  const float* xd;     // [K/32]  d8
+  const float* xs;     // [K/32]  s8 (fp16-rounded Σx, as stored by quantize_q8_1)
+  const int* xi16;     // [K/16]  Σ q8 over each 16 elements (exact)
+};
+
+__device__ __forceinline__ v4i lds_ld16(const int8_t* p) { return *(const v4i*)p; }
+__device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+__device__ __forceinline__ int dot16(const uint32_t v[4], v4i a) {
+  int s = sdot4((int)v[0], a[0], 0);
+  s = sdot4((int)v[1], a[1], s);
+  s = sdot4((int)v[2], a[2], s);
+  return sdot4((int)v[3], a[3], s);
+}
+
+// spread the low 4 bits of x to bit 4 of the four bytes of a dword
+__device__ __forceinline__ uint32_t spread4(uint32_t x) {
+  return ((x & 1) << 4) | ((x & 2) << 11) | ((x & 4) << 18) | ((x & 8) << 25);
+}
+
+// UnitDot<T>::run(row pointer, unit index u, activations) -> this lane's partial sum.
+template <int T> struct UnitDot;
+
+template <> struct UnitDot<GGQ_TYPE_Q4_0> {  // vecdotq.cuh:45-65, 347-363
+  static constexpr int UPB = 1;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)u * 18;
+    const float d4 = bits_h_f32(ld_u16(b));
+    const u32x4_a2 q = ld_u32x4(b + off::Q4_0_QS);
+    const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = q.v[i] & 0x0F0F0F0F; hi[i] = (q.v[i] >> 4) & 0x0F0F0F0F; }
+    const int sumi = dot16(lo, a0) + dot16(hi, a1);
+    return d4 * (sumi * A.xd[u] - 8 * A.xs[u]);
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_Q4_1> {  // vecdotq.cuh:69-91, 365-381
+  static constexpr int UPB = 1;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)u * 20;
+    const uint32_t dm = ld_u32(b);
+    const u32x4_a2 q = ld_u32x4(b + off::Q4_1_QS);
+    const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = q.v[i] & 0x0F0F0F0F; hi[i] = (q.v[i] >> 4) & 0x0F0F0F0F; }
+    const int sumi = dot16(lo, a0) + dot16(hi, a1);
+    const float d4d8 = (float)(bits_h(dm & 0xFFFF) * (_Float16)A.xd[u]);  // __hmul2(dm4, ds8)
+    const float m4s8 = (float)(bits_h(dm >> 16) * (_Float16)A.xs[u]);
+    return sumi * d4d8 + m4s8;
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_Q5_0> {  // vecdotq.cuh:95-124, 383-401
+  static constexpr int UPB = 1;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)u * 22;
+    const float d5 = bits_h_f32(ld_u16(b));
+    const uint32_t qh = ld_u32(b + off::Q5_0_QH);
+    const u32x4_a2 q = ld_u32x4(b + off::Q5_0_QS);
+    const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = (q.v[i] & 0x0F0F0F0F) | spread4(qh >> (4 * i));
+      hi[i] = ((q.v[i] >> 4) & 0x0F0F0F0F) | spread4(qh >> (16 + 4 * i));
+    }
+    const int sumi = dot16(lo, a0) + dot16(hi, a1);
+    return d5 * (sumi * A.xd[u] - 16 * A.xs[u]);
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_Q5_1> {  // vecdotq.cuh:128-158, 403-421
+  static constexpr int UPB = 1;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)u * 24;
+    const uint32_t dm = ld_u32(b);
+    const uint32_t qh = ld_u32(b + off::Q5_1_QH);
+    const u32x4_a2 q = ld_u32x4(b + off::Q5_1_QS);
+    const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = (q.v[i] & 0x0F0F0F0F) | spread4(qh >> (4 * i));
+      hi[i] = ((q.v[i] >> 4) & 0x0F0F0F0F) | spread4(qh >> (16 + 4 * i));
+    }
+    const int sumi = dot16(lo, a0) + dot16(hi, a1);
+    const float d5d8 = (float)(bits_h(dm & 0xFFFF) * (_Float16)A.xd[u]);
+    const float m5s8 = (float)(bits_h(dm >> 16) * (_Float16)A.xs[u]);
+    return sumi * d5d8 + m5s8;
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_Q8_0> {  // vecdotq.cuh:162-174, 423-438
+  static constexpr int UPB = 1;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)u * 34;
+    const float d = bits_h_f32(ld_u16(b));
+    const u32x4_a2 q0 = ld_u32x4(b + off::Q8_0_QS), q1 = ld_u32x4(b + off::Q8_0_QS + 16);
+    const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
+    const int sumi = dot16(q0.v, a0) + dot16(q1.v, a1);
+    return d * A.xd[u] * sumi;
+  }
+};
+
+// Q2_K / Q3_K: unit = 16 bytes of qs = bytes 16c..16c+15 of half n -> for each bit pair j
+// the 16 elements 128n + 32j + 16c + (0..15) of q8 group 4n+j.
+template <> struct UnitDot<GGQ_TYPE_Q2_K> {  // vecdotq.cuh:195-223, 440-462
+  static constexpr int UPB = 4;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const int ib = u >> 2, n = (u >> 1) & 1, c = u & 1;
+    const uint8_t* b = row + (int64_t)ib * 84;
+    const u32x4_a2 q = ld_u32x4(b + off::Q2_K_QS + 32 * n + 16 * c);
+    const u32x2_a2 sc8 = ld_u32x2(b + off::Q2_K_SC + 8 * n);  // scales of this half
+    const uint32_t dm = ld_u32(b + off::Q2_K_D);
+    float sumf_d = 0.0f, sumf_m = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = 8 * ib + 4 * n + j;  // q8 group
+      const int sidx = 2 * j + c;        // scale byte within the half
+      const int sc = (sc8.v[sidx >> 2] >> (8 * (sidx & 3))) & 0xFF;
+      const v4i a = lds_ld16(A.xq + 32 * g + 16 * c);
+      uint32_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (q.v[i] >> (2 * j)) & 0x03030303;
+      const float d8 = A.xd[g];
+      sumf_d += d8 * (float)(dot16(v, a) * (sc & 0xF));
+      sumf_m += d8 * (float)(A.xi16[2 * g + c] * (sc >> 4));
+    }
+    return bits_h_f32(dm & 0xFFFF) * sumf_d - bits_h_f32(dm >> 16) * sumf_m;
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_Q3_K> {  // vecdotq.cuh:227-260, 464-490
+  static constexpr int UPB = 4;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const int ib = u >> 2, n = (u >> 1) & 1, c = u & 1;
+    const uint8_t* b = row + (int64_t)ib * 110;
+    const u32x4_a2 q = ld_u32x4(b + off::Q3_K_QS + 32 * n + 16 * c);
+    const u32x4_a2 hm = ld_u32x4(b + off::Q3_K_HM + 16 * c);
+    const u32x3_a2 s = ld_u32x3(b + off::Q3_K_SC);
+    const float d = bits_h_f32(ld_u16(b + off::Q3_K_D));
+    float sumf = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = 8 * ib + 4 * n + j;
+      const int sc = q3k_scale(s.v[0], s.v[1], s.v[2], 8 * n + 2 * j + c);
+      const v4i a = lds_ld16(A.xq + 32 * g + 16 * c);
+      uint32_t v[4], nb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = (q.v[i] >> (2 * j)) & 0x03030303;
+        nb[i] = ((~hm.v[i]) >> (4 * n + j)) & 0x01010101;  // 1 where the mask bit is clear
+      }
+      const int dot = dot16(v, a) - 4 * dot16(nb, a);  // Σ (q2 - 4·¬h) q8
+      sumf += A.xd[g] * (float)(dot * sc);
+    }
+    return d * sumf;
+  }
+};
+
+// Q4_K / Q5_K: unit = 16 bytes of qs = bytes 16hf..16hf+15 of segment il -> 16 elements of
+// group 2il (low nibbles) and 16 of group 2il+1 (high nibbles), positions 16hf..16hf+15.
+template <> struct UnitDot<GGQ_TYPE_Q4_K> {  // vecdotq.cuh:264-291, 492-537
+  static constexpr int UPB = 8;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const int ib = u >> 3, il = (u >> 1) & 3, hf = u & 1;
+    const uint8_t* b = row + (int64_t)ib * 144;
+    const u32x4_a2 hd = ld_u32x4(b);
+    const u32x4_a2 q = ld_u32x4(b + off::Q4_K_QS + 32 * il + 16 * hf);
+    float sumf_d = 0.0f, sumf_m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gl = 2 * il + i, g = 8 * ib + gl;
+      int sc, mn;
+      k4_scale_min(hd.v[1], hd.v[2], hd.v[3], gl, sc, mn);
+      const v4i a = lds_ld16(A.xq + 32 * g + 16 * hf);
+      uint32_t v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (q.v[e] >> (4 * i)) & 0x0F0F0F0F;
+      const float d8 = A.xd[g];
+      sumf_d += d8 * (float)(dot16(v, a) * sc);
+      sumf_m += d8 * (float)(A.xi16[2 * g + hf] * mn);
+    }
+    return bits_h_f32(hd.v[0] & 0xFFFF) * sumf_d - bits_h_f32(hd.v[0] >> 16) * sumf_m;
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_Q5_K> {  // vecdotq.cuh:295-323, 539-585
+  static constexpr int UPB = 8;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const int ib = u >> 3, il = (u >> 1) & 3, hf = u & 1;
+    const uint8_t* b = row + (int64_t)ib * 176;
+    const u32x4_a2 hd = ld_u32x4(b);
+    const u32x4_a2 q = ld_u32x4(b + off::Q5_K_QS + 32 * il + 16 * hf);
+    const u32x4_a2 qh = ld_u32x4(b + off::Q5_K_QH + 16 * hf);
+    float sumf_d = 0.0f, sumf_m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gl = 2 * il + i, g = 8 * ib + gl;
+      int sc, mn;
+      k4_scale_min(hd.v[1], hd.v[2], hd.v[3], gl, sc, mn);
+      const v4i a = lds_ld16(A.xq + 32 * g + 16 * hf);
+      uint32_t v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = ((q.v[e] >> (4 * i)) & 0x0F0F0F0F) | (((qh.v[e] >> gl) & 0x01010101) << 4);
+      const float d8 = A.xd[g];
+      sumf_d += d8 * (float)(dot16(v, a) * sc);
+      sumf_m += d8 * (float)(A.xi16[2 * g + hf] * mn);
+    }
+    return bits_h_f32(hd.v[0] & 0xFFFF) * sumf_d - bits_h_f32(hd.v[0] >> 16) * sumf_m;
+  }
+};
+// Q6_K: unit = 16 bytes of ql = bytes 16c..16c+15 (c = 0..3) of half ip -> low nibbles: 16
+// elements of group 4ip + c/2, high nibbles: 16 elements of group 4ip + 2 + c/2, positions 16(c&1)..
+template <> struct UnitDot<GGQ_TYPE_Q6_K> {  // vecdotq.cuh:327-345, 587-605
+  static constexpr int UPB = 8;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const int ib = u >> 3, ip = (u >> 2) & 1, c = u & 3;
+    const uint8_t* b = row + (int64_t)ib * 210;
+    const u32x4_a2 ql = ld_u32x4(b + off::Q6_K_QL + 64 * ip + 16 * c);
+    const u32x4_a2 qh = ld_u32x4(b + off::Q6_K_QH + 32 * ip + 16 * (c & 1));
+    const float d = bits_h_f32(ld_u16(b + off::Q6_K_D));
+    float sumf = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = (c >> 1) + 2 * i;          // 32-element group inside the half
+      const int g = 8 * ib + 4 * ip + j;
+      const int sc = (int8_t)b[off::Q6_K_SC + 8 * ip + 2 * j + (c & 1)];
+      const v4i a = lds_ld16(A.xq + 32 * g + 16 * (c & 1));
+      uint32_t v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = ((ql.v[e] >> (4 * i)) & 0x0F0F0F0F) | (((qh.v[e] >> (2 * j)) & 0x03030303) << 4);
+      const int dot = dot16(v, a) - 32 * A.xi16[2 * g + (c & 1)];  // Σ (q6 - 32) q8
+      sumf += A.xd[g] * (float)(dot * sc);
+    }
+    return d * sumf;
+  }
+};
+
+// LDS bytes for a row of k activations: int8[k] + float[k/32]*2 + int[k/16]
+static inline size_t mmvq_lds_bytes(int64_t k) { return (size_t)k + (size_t)(k / 32) * 8 + (size_t)(k / 16) * 4; }
+
+template <int T, int DT, int ROWS>
+__global__ void __launch_bounds__(256) mmvq_kernel(const uint8_t* __restrict__ w,
+                                                   const uint8_t* __restrict__ q8,
+                                                   void* __restrict__ y, int k, int n_rows,
+                                                   int rows_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  int8_t* xq = (int8_t*)lds;
+  float* xd = (float*)(lds + k);
+  float* xs = xd + k / 32;
+  int* xi16 = (int*)(xs + k / 32);
+
+  // ---- stage the Q8_1 row: block_q8_1 {half d, half s, int8 qs[32]} -> de-interleaved ----
+  for (int i = threadIdx.x; i < k / 4; i += 256) {
+    const int g = i >> 3, j = i & 7;
+    ((uint32_t*)xq)[i] = *(const uint32_t*)(q8 + (int64_t)g * 36 + 4 + 4 * j);
+  }
+  for (int g = threadIdx.x; g < k / 32; g += 256) {
+    const uint32_t ds = *(const uint32_t*)(q8 + (int64_t)g * 36);
+    xd[g] = bits_h_f32(ds & 0xFFFF);
+    xs[g] = bits_h_f32(ds >> 16);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k / 16; i += 256) {
+    const v4i a = *(const v4i*)(xq + 16 * i);
+    int s = sdot4(0x01010101, a[0], 0);
+    s = sdot4(0x01010101, a[1], s);
+    s = sdot4(0x01010101, a[2], s);
+    xi16[i] = sdot4(0x01010101, a[3], s);
+  }
+  __syncthreads();
+  const ActLds A{xq, xd, xs, xi16};
+
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int units = k / Fmt<T>::QK * UnitDot<T>::UPB;
+  const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
+  const int row_end = min(n_rows, (wave + 1) * rows_per_wave);
+
+  for (int r0 = wave * rows_per_wave; r0 < row_end; r0 += ROWS) {
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+    for (int u = lane; u < units; u += 64) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int row = min(r0 + r, n_rows - 1);  // clamp: duplicate work, never out of bounds
+        acc[r] += UnitDot<T>::run(w + row * row_bytes, u, A);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const float tot = wave_sum(acc[r]);
+      if (lane == 0 && r0 + r < row_end) Elem<DT>::st(y, r0 + r, tot);
+    }
+  }
+}
+
+template <int T, int DT>
+static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int64_t n, hipStream_t s) {
+  constexpr int ROWS = 2;
+  const size_t lds = mmvq_lds_bytes(k);
+  if (lds > 160 * 1024) return GGQ_ERR_SHAPE;
+  // ~2-4 workgroups per CU (256 CUs x 4 waves): rows_per_wave = n / 2048, even, in [2, 16]
+  int rpw = (int)(n / 2048);
+  rpw = rpw < ROWS ? ROWS : (rpw > 16 ? 16 : rpw);
+  rpw = (rpw + ROWS - 1) / ROWS * ROWS;
+  const int64_t waves = (n + rpw - 1) / rpw;
+  const int64_t grid = (waves + 3) / 4;
+  auto kern = mmvq_kernel<T, DT, ROWS>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GGQ_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, (const uint8_t*)w,
+                     (const uint8_t*)q8, y, (int)k, (int)n, rpw);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
+}
+
+template <int T>
+static int launch_mmvq(const void* w, const void* q8, void* y, int dt, int64_t k, int64_t n, hipStream_t s) {
+  switch (dt) {
+    case GGQ_F32: return launch_mmvq_t<T, GGQ_F32>(w, q8, y, k, n, s);
+    case GGQ_F16: return launch_mmvq_t<T, GGQ_F16>(w, q8, y, k, n, s);
+    case GGQ_BF16: return launch_mmvq_t<T, GGQ_BF16>(w, q8, y, k, n, s);
+    default: return GGQ_ERR_DTYPE;
+  }
+}
+
+}  // namespace ggq
+
+extern "C" int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, int dtype,
+                                          int64_t k, int64_t n_rows, void* stream) {
+  using namespace ggq;
+  if (k <= 0 || n_rows < 0) return GGQ_ERR_ARG;
+  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
+  if (k > 0x7fffffffLL / 64 || n_rows > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (n_rows == 0) return GGQ_OK;
+  if (!w || !q || !y) return GGQ_ERR_ARG;
+  if (((uintptr_t)w & 1) || ((uintptr_t)q & 3)) return GGQ_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  switch (type) {
+    case GGQ_TYPE_Q4_0: return launch_mmvq<GGQ_TYPE_Q4_0>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q4_1: return launch_mmvq<GGQ_TYPE_Q4_1>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q5_0: return launch_mmvq<GGQ_TYPE_Q5_0>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q5_1: return launch_mmvq<GGQ_TYPE_Q5_1>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q8_0: return launch_mmvq<GGQ_TYPE_Q8_0>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q2_K: return launch_mmvq<GGQ_TYPE_Q2_K>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q3_K: return launch_mmvq<GGQ_TYPE_Q3_K>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q4_K: return launch_mmvq<GGQ_TYPE_Q4_K>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q5_K: return launch_mmvq<GGQ_TYPE_Q5_K>(w, q, y, dtype, k, n_rows, s);
+    case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, s);
+    default: return GGQ_ERR_TYPE;
+  }
+}
+
+extern "C" int ggq_mul_mat_vec_q(const void* w, const void* x, void* y, int type, int dtype,
+                                 int64_t k, int64_t n_rows, void* scratch, void* stream) {
+  if (!scratch) return GGQ_ERR_ARG;
+  int rc = ggq_quantize_q8_1(x, dtype, scratch, 1, k, stream);
+  if (rc != GGQ_OK) return rc;
+  return ggq_mul_mat_vec_q_prequant(w, scratch, y, type, dtype, k, n_rows, stream);
+}

@@ -1,0 +1,140 @@
+// quantize.hip — activations (fp32/fp16/bf16) -> Q8_1 int8 blocks, gfx950.
+//
+// Replaces quantize_q8_1 / quantize_row_q8_1_cuda (HK/ggml/ggml_kernel.cu:13-66) and
+// quantize_mmq_q8_1 / quantize_mmq_q8_1_cuda (HK/ggml/mmq.cu:109-177).
+//
+// Bit-exactness contract: per 32 elements d = amax/127 (IEEE fp32 divide),
+// q = roundf(x/d) (0 when amax == 0), sum = the reference's 32-lane xor-butterfly
+// (masks 16,8,4,2,1) in fp32 — reproduced here as the same pairing tree.
+//
+// Mapping: one lane owns 4 consecutive elements (one 16/8-byte load, one dword of
+// int8 out), 8 lanes form a 32-element group, a wave covers 256 elements.  Butterfly
+// levels 16/8/4 are lane exchanges (xor 4/2/1 in lane units), levels 2/1 are in-lane.
+#include "ggq_common.h"
+
+namespace ggq {
+
+template <int DT>
+__device__ __forceinline__ void load4(const void* x, int64_t base, int64_t ix, int64_t k, float v[4]) {
+  // elements ix..ix+3 of a row of k (zero beyond k: the reference pads with zeros)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (ix + i < k) ? Elem<DT>::ld(x, base + ix + i) : 0.0f;
+}
+
+// LAYOUT 0: block_q8_1 {half d; half s; int8 qs[32]}, row-major [batch][padded/32]
+// LAYOUT 1: block_q8_1_mmq {half2 ds[4]; int8 qs[128]}, index (ix/128)*batch + token
+template <int DT, int LAYOUT, bool NEED_SUM>
+__global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restrict__ x,
+                                                            uint8_t* __restrict__ q, int64_t batch,
+                                                            int64_t k, int64_t padded, int64_t tok_off) {
+  const int64_t t = blockIdx.y + tok_off;
+  const int64_t ix = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (ix >= padded) return;  // padded % 32 == 0, so a 32-group is never split by this exit
+  float v[4];
+  load4<DT>(x, t * k, ix, k, v);
+
+  float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+
+  float sum = 0.0f;
+  if (NEED_SUM) {
+    float s[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int m = 4; m > 0; m >>= 1) {  // element masks 16, 8, 4
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] = s[i] + __shfl_xor(s[i], m, 64);
+    }
+    // element mask 2: (e, e^2) -> s0+s2, s1+s3 ; element mask 1: their sum
+    sum = (s[0] + s[2]) + (s[1] + s[3]);
+  }
+
+  const float d = amax / 127;
+  int qi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qi[i] = amax == 0.0f ? 0 : (int)roundf(v[i] / d);
+  const uint32_t packed = (uint32_t)(qi[0] & 0xFF) | ((uint32_t)(qi[1] & 0xFF) << 8) |
+                          ((uint32_t)(qi[2] & 0xFF) << 16) | ((uint32_t)(qi[3] & 0xFF) << 24);
+
+  const int64_t g = ix >> 5;       // 32-element group index in the row
+  const int e = (int)(ix & 31);    // element offset inside the group
+  if (LAYOUT == 0) {
+    uint8_t* blk = q + (t * (padded >> 5) + g) * 36;
+    *(uint32_t*)(blk + 4 + e) = packed;
+    if (e == 0) {
+      const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+      const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
+      *(uint32_t*)blk = (uint32_t)hd | ((uint32_t)hs << 16);
+    }
+  } else {
+    uint8_t* blk = q + ((g >> 2) * batch + t) * 144;
+    const int slot = (int)(g & 3);
+    *(uint32_t*)(blk + 16 + 32 * slot + e) = packed;
+    if (e == 0) {
+      if (NEED_SUM) {
+        const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+        const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
+        *(uint32_t*)(blk + 4 * slot) = (uint32_t)hd | ((uint32_t)hs << 16);
+      } else {
+        *(float*)(blk + 4 * slot) = d;
+      }
+    }
+  }
+}
+
+template <int LAYOUT, bool NEED_SUM>
+static int launch_quant(const void* x, int dt, void* q, int64_t batch, int64_t k, int64_t padded,
+                        hipStream_t s) {
+  if (batch == 0) return GGQ_OK;
+  const dim3 block(256);
+  const unsigned gx = (unsigned)((padded / 4 + 255) / 256);
+  for (int64_t off = 0; off < batch; off += 65535) {  // grid.y limit, as ggml_kernel.cu:56-64
+    const int64_t nb = batch - off < 65535 ? batch - off : 65535;
+    const dim3 grid(gx, (unsigned)nb);
+    const void* xo = x;
+    uint8_t* qo = (uint8_t*)q;
+    switch (dt) {
+      case GGQ_F32:
+        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F32, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
+        break;
+      case GGQ_F16:
+        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
+        break;
+      case GGQ_BF16:
+        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_BF16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
+        break;
+      default: return GGQ_ERR_DTYPE;
+    }
+    GGQ_HIP_CHECK_LAUNCH();
+  }
+  return GGQ_OK;
+}
+
+}  // namespace ggq
+
+extern "C" int ggq_quantize_q8_1(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                                 void* stream) {
+  using namespace ggq;
+  if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
+  if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (batch == 0) return GGQ_OK;
+  if (!x || !q) return GGQ_ERR_ARG;
+  if ((uintptr_t)q & 3) return GGQ_ERR_ALIGN;
+  return launch_quant<0, true>(x, x_dtype, q, batch, k, ggq_mmvq_padded_k(k), (hipStream_t)stream);
+}
+
+extern "C" int ggq_quantize_q8_1_mmq(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                                     int type, void* stream) {
+  using namespace ggq;
+  if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
+  if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (batch == 0) return GGQ_OK;
+  if (!x || !q) return GGQ_ERR_ARG;
+  if ((uintptr_t)q & 15) return GGQ_ERR_ALIGN;
+  const int64_t padded = ggq_mmq_padded_k(k);
+  if (ggq_mmq_need_sum(type))
+    return launch_quant<1, true>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream);
+  return launch_quant<1, false>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream);
+}

@@ -1,0 +1,97 @@
+"""Row-sharded (output-feature-parallel) quantised matmul across the GPUs of one node.
+
+The reference has no multi-device code at all (zero NCCL/MPI call sites);
+this is the north_star's "weight columns shard across the GPUs with an RCCL all-gather of
+partial outputs": rank r owns the weight rows [r·N/P, (r+1)·N/P) — any row split is
+format-safe because a row is a whole number of blocks — computes its [batch, N/P] slab with
+the single-GPU kernels, and the slabs are all-gathered.  One process per GPU,
+``torch.distributed`` backend "nccl" (= RCCL over xGMI); no collective touches the weights.
+
+The partition / gather logic is plain torch.distributed code and runs on CPU tensors with
+the gloo backend too (that is how tests/test_dist_cpu.py covers it without GPUs).
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """[start, end) of the weight rows owned by `rank`: an even split, the first
+    n_rows % world_size ranks take one extra row."""
+    base, rem = divmod(n_rows, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def gather_slabs(y_local: torch.Tensor, n_rows: int, group=None, out: Optional[torch.Tensor] = None,
+                 async_op: bool = False):
+    """All-gather the per-rank [batch, rows_r] slabs into [batch, n_rows].
+
+    Equal shards use one all_gather_into_tensor into a [P, batch, N/P] buffer that is
+    returned as a [batch, N] *view* (permute, no copy when P == 1); ragged shards fall
+    back to all_gather with per-rank tensors.  Returns (y_full, work_or_None)."""
+    world = dist.get_world_size(group)
+    batch = y_local.shape[0]
+    if world == 1:
+        return y_local, None
+    if n_rows % world == 0:
+        rows = n_rows // world
+        assert y_local.shape == (batch, rows)
+        buf = out if out is not None else torch.empty((world, batch, rows), dtype=y_local.dtype,
+                                                      device=y_local.device)
+        work = dist.all_gather_into_tensor(buf, y_local.contiguous(), group=group, async_op=async_op)
+        return buf.permute(1, 0, 2).reshape(batch, n_rows) if not async_op else buf, work
+    parts = []
+    for r in range(world):
+        s, e = shard_rows(n_rows, world, r)
+        parts.append(torch.empty((batch, e - s), dtype=y_local.dtype, device=y_local.device))
+    work = dist.all_gather(parts, y_local.contiguous(), group=group, async_op=async_op)
+    if async_op:
+        return parts, work
+    return torch.cat(parts, dim=1), None
+
+
+def unpermute_gathered(buf: torch.Tensor) -> torch.Tensor:
+    """[P, batch, rows] gather buffer -> [batch, P*rows]"""
+    p, b, r = buf.shape
+    return buf.permute(1, 0, 2).reshape(b, p * r)
+
+
+class RowShardedQuantLinear:
+    """y[batch, N] = x[batch, K] · W[N, K]^T with W row-sharded over the process group.
+
+    `matmul` defaults to the drop-in GPU op (ggml.ggml_mul_mat_a8 / ggml_mul_mat_vec_a8);
+    tests inject a CPU function with the same signature."""
+
+    def __init__(self, w_shard: torch.Tensor, quant_type: int, n_rows: int, group=None,
+                 matmul: Optional[Callable] = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.quant_type = int(quant_type)
+        self.n_rows = n_rows
+        self.start, self.end = shard_rows(n_rows, self.world, self.rank)
+        assert w_shard.shape[0] == self.end - self.start, "w_shard must hold exactly this rank's rows"
+        self.w = w_shard
+        self._matmul = matmul
+
+    @staticmethod
+    def shard_weight(w_full, n_rows: int, world: int, rank: int):
+        s, e = shard_rows(n_rows, world, rank)
+        return w_full[s:e]
+
+    def local(self, x: torch.Tensor) -> torch.Tensor:
+        if self._matmul is not None:
+            return self._matmul(self.w, x, self.quant_type, self.end - self.start)
+        import ggml
+        if x.dim() == 2 and x.size(0) == 1:
+            return ggml.ggml_mul_mat_vec_a8(self.w, x, self.quant_type, self.end - self.start)
+        return ggml.ggml_mul_mat_a8(self.w, x, self.quant_type, self.end - self.start)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.local(x)
+        if self.world == 1:
+            return y
+        full, _ = gather_slabs(y.reshape(-1, y.shape[-1]), self.n_rows, self.group)
+        return full.reshape(*y.shape[:-1], self.n_rows)

@@ -17,17 +17,18 @@ _F16_FIELDS = {
 }
 
 
-def random_blocks(t, n_blocks, seed=0):
-    """uint8 [n_blocks, block_bytes] of valid blocks."""
+def random_blocks(t, n_blocks, seed=0, d_scale=1.0):
+    """uint8 [n_blocks, block_bytes] of valid blocks.  d_scale multiplies the fp16 block
+    scales (d, m/dmin) — the K-quant recipe yields |w| up to ~16, real checkpoints are ~1e-2."""
     t = GGMLType(int(t))
     _, bs = BLOCK[t]
     rng = np.random.default_rng(seed)
     b = rng.integers(0, 256, size=(n_blocks, bs), dtype=np.uint8)
     d_off, m_off = _F16_FIELDS[t]
-    d = (rng.uniform(0.5, 2.0, n_blocks) * 2.0 ** -8).astype(np.float16)
+    d = (rng.uniform(0.5, 2.0, n_blocks) * 2.0 ** -8 * d_scale).astype(np.float16)
     b[:, d_off:d_off + 2] = d.view(np.uint8).reshape(n_blocks, 2)
     if m_off is not None:
-        m = (rng.uniform(-1.0, 1.0, n_blocks) * 2.0 ** -6).astype(np.float16)
+        m = (rng.uniform(-1.0, 1.0, n_blocks) * 2.0 ** -6 * d_scale).astype(np.float16)
         b[:, m_off:m_off + 2] = m.view(np.uint8).reshape(n_blocks, 2)
     if t == GGMLType.Q6_K:
         sc = rng.integers(-64, 64, size=(n_blocks, 16), dtype=np.int8)
@@ -35,11 +36,11 @@ def random_blocks(t, n_blocks, seed=0):
     return b
 
 
-def random_weight(t, n_rows, k, seed=0):
+def random_weight(t, n_rows, k, seed=0, d_scale=1.0):
     """uint8 [n_rows, row_bytes] — the shape a GGUF ReaderTensor.data has."""
     qk, bs = BLOCK[GGMLType(int(t))]
     assert k % qk == 0
-    return random_blocks(t, n_rows * (k // qk), seed).reshape(n_rows, (k // qk) * bs)
+    return random_blocks(t, n_rows * (k // qk), seed, d_scale).reshape(n_rows, (k // qk) * bs)
 
 
 def edge_blocks(t):

@@ -1,0 +1,116 @@
+"""The drop-in operator surface on the GPU: written to read like the reference's own
+tests (HK/tests/kernels/test_cuda_kernels.py) — same calls, same tolerances — with the
+GGUF sample files replaced by synthetic block-valid tensors and gguf.dequantize by its
+numpy restatement (oracle/ggq_numpy.py)."""
+import numpy as np
+import pytest
+import torch
+
+from ggq import synth
+from ggq.formats import GGMLType, WEIGHT_TYPES
+from oracle import ggq_numpy as N
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.half, torch.bfloat16, torch.float32]
+HIDDEN_SIZES = [256, 1024]
+NUM_TOKENS = [7, 83, 128, 2048]
+QUANT_TYPES = WEIGHT_TYPES  # the reference lists Q2_K..Q6_K, Q4_0, Q5_0, Q8_0; Q4_1/Q5_1 added
+
+
+def sample_tensors(hidden_size, quant_type):
+    """stand-in for get_gguf_sample_tensors: a few [rows, hidden] tensors.  The reference's
+    absolute tolerances (atol = 1) are tuned to its sample checkpoints, so the K-quant block
+    scales are shrunk until |w| <~ 1 like a real tensor (the default recipe reaches |w| ~ 16)."""
+    d_scale = 2.0 ** -4 if int(quant_type) >= 10 else 1.0
+    return [(rows, synth.random_weight(quant_type, rows, hidden_size, seed=rows, d_scale=d_scale))
+            for rows in (hidden_size, 96)]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ggml
+    return ggml
+
+
+@pytest.mark.parametrize("hidden_size", HIDDEN_SIZES)
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("quant_type", QUANT_TYPES, ids=lambda t: t.name)
+@torch.inference_mode()
+def test_dequantize(ops, hidden_size, dtype, quant_type):
+    for rows, data in sample_tensors(hidden_size, quant_type):
+        ref_output = torch.tensor(N.gguf_dequantize(data, quant_type).reshape(rows, hidden_size), device="cuda").to(dtype)
+        output = ops.ggml_dequantize(torch.tensor(data, device="cuda"), quant_type, rows, hidden_size).to(dtype)
+        torch.testing.assert_close(output, ref_output, atol=1e-2, rtol=4e-2)
+
+
+@pytest.mark.parametrize("hidden_size", HIDDEN_SIZES)
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("quant_type", QUANT_TYPES, ids=lambda t: t.name)
+@torch.inference_mode()
+def test_mmvq(ops, hidden_size, dtype, quant_type):
+    torch.manual_seed(0)
+    x = torch.rand((1, hidden_size), dtype=dtype, device="cuda")
+    for rows, data in sample_tensors(hidden_size, quant_type):
+        weight = torch.tensor(N.gguf_dequantize(data, quant_type).reshape(rows, hidden_size), device="cuda").to(dtype)
+        ref_output = x @ weight.T
+        qweight = torch.tensor(data, device="cuda")
+        output = ops.ggml_mul_mat_vec_a8(qweight, x, quant_type, qweight.shape[0]).to(dtype)
+        torch.testing.assert_close(output, ref_output, atol=1, rtol=1e-1)
+
+
+@pytest.mark.parametrize("num_tokens", NUM_TOKENS)
+@pytest.mark.parametrize("hidden_size", HIDDEN_SIZES)
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("quant_type", QUANT_TYPES, ids=lambda t: t.name)
+@torch.inference_mode()
+def test_mmq(ops, num_tokens, hidden_size, dtype, quant_type):
+    torch.manual_seed(0)
+    x = torch.rand((num_tokens, hidden_size), dtype=dtype, device="cuda")
+    for rows, data in sample_tensors(hidden_size, quant_type):
+        weight = torch.tensor(N.gguf_dequantize(data, quant_type).reshape(rows, hidden_size), device="cuda").to(dtype)
+        ref_output = x @ weight.T
+        qweight = torch.tensor(data, device="cuda")
+        output = ops.ggml_mul_mat_a8(qweight, x, quant_type, qweight.shape[0]).to(dtype)
+        atols = {torch.half: 1, torch.bfloat16: 1.5, torch.float: 1.2}
+        rtols = {torch.half: 1e-1, torch.bfloat16: 1e4, torch.float: 2e1}
+        torch.testing.assert_close(output, ref_output, atol=atols[dtype], rtol=rtols[dtype])
+
+
+@pytest.mark.parametrize("batch_size", [2, 8])
+@pytest.mark.parametrize("num_tokens", [7, 128])
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("quant_type", [GGMLType.Q4_K, GGMLType.Q6_K, GGMLType.Q4_0, GGMLType.Q8_0], ids=lambda t: t.name)
+@torch.inference_mode()
+def test_mmq_batching(ops, batch_size, num_tokens, dtype, quant_type):
+    hidden_size = 256
+    torch.manual_seed(0)
+    x = torch.rand((batch_size, num_tokens, hidden_size), dtype=dtype, device="cuda")
+    for rows, data in sample_tensors(hidden_size, quant_type):
+        weight = torch.tensor(N.gguf_dequantize(data, quant_type).reshape(rows, hidden_size), device="cuda").to(dtype)
+        ref_output = x @ weight.T
+        qweight = torch.tensor(data, device="cuda")
+        output = ops.ggml_mul_mat_a8(qweight, x, quant_type, qweight.shape[0]).to(dtype)
+        assert output.shape == (batch_size, num_tokens, rows)
+        atols = {torch.half: 1, torch.bfloat16: 2, torch.float: 1}
+        rtols = {torch.half: 1e-1, torch.bfloat16: 1e-1, torch.float: 2e-1}
+        torch.testing.assert_close(output, ref_output, atol=atols[dtype], rtol=rtols[dtype])
+        # 3-D call == 2-D call on the flattened tokens, bit for bit
+        flat = ops.ggml_mul_mat_a8(qweight, x.reshape(-1, hidden_size), quant_type, rows)
+        assert torch.equal(flat.reshape(batch_size, num_tokens, rows), output)
+
+
+def test_op_errors(ops):
+    w = torch.zeros((4, 18 * 8), dtype=torch.uint8, device="cuda")
+    x = torch.zeros((1, 256), dtype=torch.float16, device="cuda")
+    with pytest.raises(AssertionError):
+        ops.ggml_mul_mat_vec_a8(w, torch.zeros((2, 256), dtype=torch.float16, device="cuda"), 2, 4)
+    with pytest.raises(RuntimeError):
+        ops.ggml_dequantize(w, 5, 4, 256)  # unsupported type id
+    with pytest.raises(RuntimeError):
+        ops.ggml_mul_mat_a8(w, x.to(torch.float64), 2, 4)
+    with pytest.raises(RuntimeError):
+        ops.ggml_mul_mat_a8(w, torch.zeros((256,), dtype=torch.float16, device="cuda"), 2, 4)  # 1-D X
+    with pytest.raises(RuntimeError):
+        ops.ggml_mul_mat_a8(w[:, :100].contiguous(), x, 2, 4)  # wrong byte count
+    assert ops.ggml_mul_mat_a8(w, x[:0], 2, 4).shape == (0, 4)

@@ -1,0 +1,187 @@
+"""GPU parity tests proper: the hand-written HIP path, called through the C ABI
+(include/ggq.h), against the oracle on the same seeded inputs.
+
+  integer / byte work (dequantise bit patterns, Q8_1 bytes)  -> bit-exact
+  fp accumulate (MMVQ / MMQ)                                  -> 1e-3 relative (north_star)
+"""
+import numpy as np
+import pytest
+import torch
+
+from ggq import synth
+from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM, row_bytes
+import util
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16, torch.float32]
+
+
+def _x(shape, dtype, seed=0, kind="randn"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(shape, generator=g) if kind == "randn" else torch.rand(shape, generator=g)
+    return x.to(dtype).cuda()
+
+
+# ---------------------------------------------------------------- dequantise
+@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+def test_dequantize_bit_exact(oracle, t):
+    qk, bs = BLOCK[t]
+    blocks = np.concatenate([synth.random_blocks(t, 777, seed=11), synth.edge_blocks(t)])
+    nb = blocks.shape[0]
+    got = util.gpu_dequant(blocks, t, 1, nb * qk).reshape(-1)
+    ref = oracle.dequantize_f16(blocks, t, nb * qk)
+    assert util.same_nan(got, ref), f"{t.name}: fp16 bit patterns differ from the oracle"
+
+
+@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+def test_dequantize_ragged_and_tiny(oracle, t):
+    qk, _ = BLOCK[t]
+    for nb in (1, 2, 3, 65):  # fewer chunks than one workgroup / odd counts
+        blocks = synth.random_blocks(t, nb, seed=nb)
+        got = util.gpu_dequant(blocks, t, nb, qk).reshape(-1)
+        assert util.same_nan(got, oracle.dequantize_f16(blocks, t, nb * qk))
+
+
+def test_dequantize_empty_and_errors():
+    from ggq import lib
+    L = lib.hip()
+    assert L.ggq_dequantize_f16(None, None, 2, 0, 0, None) == 0
+    assert L.ggq_dequantize_f16(None, None, 5, 1, 32, None) == -1   # unsupported type
+    assert L.ggq_dequantize_f16(None, None, 12, 1, 32, None) == -2  # 32 % 256 != 0
+    assert L.ggq_dequantize_f16(None, None, 2, 1, 32, None) == -4   # null pointers
+
+
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K], ids=lambda t: t.name)
+def test_dequantize_full_size(oracle, t):
+    """BASELINE config 2 shape: 11008 x 4096 (45 M elements), checked bit-exact in full."""
+    n_rows, k = 11008, 4096
+    w = synth.random_weight(t, n_rows, k, seed=5)
+    got = util.gpu_dequant(w, t, n_rows, k)
+    ref = oracle.dequantize_f16(w, t, n_rows * k).reshape(n_rows, k)
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+
+
+# ---------------------------------------------------------------- Q8_1 quantiser
+def _edge_rows(k, dtype):
+    x = torch.zeros((6, k), dtype=torch.float32)
+    x[1, 5] = 3.0                      # single spike
+    x[2, :] = 1.0                      # constant
+    x[3, :32] = torch.arange(32) - 15.5  # ties at .5 after scaling
+    x[4, :] = torch.linspace(-1, 1, k)
+    n5 = min(64, k)
+    x[5, :n5] = torch.tensor([127.0, -127.0] * (n5 // 2))
+    return x.to(dtype).cuda()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("k", [32, 96, 1000, 4096])
+def test_quantize_q8_1_bit_exact(oracle, dtype, k):
+    for x in (_x((5, k), dtype, seed=k), _edge_rows(k, dtype)):
+        got = util.gpu_quantize_q8_1(x)
+        ref = oracle.quantize_q8_1(x.float().cpu().numpy())
+        assert np.array_equal(got, ref), "block_q8_1 bytes differ from the oracle"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0], ids=lambda t: t.name)  # need_sum / not
+@pytest.mark.parametrize("batch,k", [(1, 256), (7, 1024), (130, 4096), (3, 992)])
+def test_quantize_q8_1_mmq_bit_exact(oracle, dtype, t, batch, k):
+    x = _x((batch, k), dtype, seed=batch + k)
+    got = util.gpu_quantize_q8_1_mmq(x, t)
+    ref = oracle.quantize_q8_1_mmq(x.float().cpu().numpy(), t)
+    assert np.array_equal(got, ref), "block_q8_1_mmq bytes differ from the oracle"
+
+
+# ---------------------------------------------------------------- MMVQ
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("k,n_rows", [(256, 37), (1024, 64), (4096, 130)])
+def test_mmvq_vs_oracle(oracle, dtype, t, k, n_rows):
+    w = synth.random_weight(t, n_rows, k, seed=k + n_rows)
+    x = _x((1, k), dtype, seed=1)
+    y = util.gpu_mmvq(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_vec_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref.reshape(1, -1), yabs.reshape(1, -1), dtype, f"mmvq {t.name}")
+
+
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q5_1, GGMLType.Q8_0], ids=lambda t: t.name)
+def test_mmvq_k_not_multiple_of_256(oracle, t):
+    k, n_rows = 32 * 37, 19
+    w = synth.random_weight(t, n_rows, k, seed=3)
+    x = _x((1, k), torch.float32, seed=2)
+    y = util.gpu_mmvq(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_vec_q(w, x.cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref.reshape(1, -1), yabs.reshape(1, -1), torch.float32, f"mmvq {t.name}")
+
+
+# ---------------------------------------------------------------- MMQ
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("batch,k,n_rows", [(1, 256, 33), (7, 1024, 64), (33, 256, 70), (83, 1024, 40),
+                                            (128, 512, 96), (200, 256, 32)])
+def test_mmq_vs_oracle(oracle, dtype, t, batch, k, n_rows):
+    w = synth.random_weight(t, n_rows, k, seed=batch + k)
+    x = _x((batch, k), dtype, seed=4)
+    y = util.gpu_mmq(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, dtype, f"mmq {t.name} b={batch}")
+
+
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q5_0, GGMLType.Q8_0, GGMLType.Q4_1], ids=lambda t: t.name)
+def test_mmq_k_not_multiple_of_256(oracle, t):
+    batch, k, n_rows = 9, 32 * 21, 45
+    w = synth.random_weight(t, n_rows, k, seed=8)
+    x = _x((batch, k), torch.float32, seed=6)
+    y = util.gpu_mmq(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"mmq {t.name}")
+
+
+def test_mmq_integer_exact(oracle):
+    """Integer unpack + int8 MFMA contraction, bit-exact: with power-of-two scales and
+    integer-valued activations every product and partial sum is exactly representable,
+    so the GPU result must equal the oracle to the last bit."""
+    for t in WEIGHT_TYPES:
+        qk, bs = BLOCK[t]
+        n_rows, k, batch = 64, 512, 40
+        w = synth.random_weight(t, n_rows, k, seed=9).reshape(-1, bs)
+        from ggq.synth import _F16_FIELDS
+        d_off, m_off = _F16_FIELDS[t]
+        w[:, d_off:d_off + 2] = np.array([2.0 ** -4], np.float16).view(np.uint8)
+        if m_off is not None:
+            w[:, m_off:m_off + 2] = np.array([2.0 ** -3], np.float16).view(np.uint8)
+        rng = np.random.default_rng(1)
+        xi = rng.integers(-8, 9, size=(batch, k)).astype(np.float32)
+        xi[:, ::32] = 127.0  # amax = 127 in every group -> d8 = 1 exactly, q8 = x
+        x = torch.from_numpy(xi).cuda()
+        y = util.gpu_mmq(w.reshape(n_rows, -1), x, t, n_rows).cpu().numpy()
+        ref, _ = oracle.mul_mat_q(w.reshape(n_rows, -1), xi, t, n_rows)
+        assert np.array_equal(y, ref), f"{t.name}: exact-integer MMQ differs"
+
+
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q6_K, GGMLType.Q8_0], ids=lambda t: t.name)
+def test_mmq_full_size_rows_sample(oracle, t):
+    """BASELINE config 4 shape (K=4096, N=11008, batch 128): oracle on a sample of rows +
+    the row-permutation property (permuting W's rows permutes Y's columns bit-exactly)."""
+    n_rows, k, batch = 11008, 4096, 128
+    w = synth.random_weight(t, n_rows, k, seed=21)
+    x = _x((batch, k), torch.float16, seed=22)
+    y = util.gpu_mmq(w, x, t, n_rows)
+    rows = np.r_[0:40, 5000:5040, n_rows - 40:n_rows]
+    ref, yabs = oracle.mul_mat_q(w[rows], x.float().cpu().numpy(), t, len(rows))
+    util.assert_fp_accumulate(y[:, torch.from_numpy(rows).cuda()], ref, yabs, torch.float16, f"mmq full {t.name}")
+    perm = np.random.default_rng(0).permutation(n_rows)
+    y2 = util.gpu_mmq(w[perm], x, t, n_rows)
+    assert torch.equal(y2, y[:, torch.from_numpy(perm).cuda()])
+
+
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q4_K], ids=lambda t: t.name)
+def test_mmvq_full_size(oracle, t):
+    """BASELINE config 3 shape: batch 1, K=4096, N=11008."""
+    n_rows, k = 11008, 4096
+    w = synth.random_weight(t, n_rows, k, seed=31)
+    x = _x((1, k), torch.float16, seed=32)
+    y = util.gpu_mmvq(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_vec_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref.reshape(1, -1), yabs.reshape(1, -1), torch.float16, f"mmvq full {t.name}")

@@ -1,0 +1,100 @@
+"""Shared helpers of the parity tests: device buffers via torch, calls through the C ABI."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ggq import lib as ggqlib
+from ggq.formats import GGMLType, BLOCK, NEED_SUM
+
+TORCH_DT = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}
+
+
+def vp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_bytes(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+
+
+def gpu_dequant(w_np, t, m, n):
+    L = ggqlib.hip()
+    w = dev_bytes(w_np)
+    out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    ggqlib.check(L.ggq_dequantize_f16(vp(w), vp(out), int(t), m, n, stream_ptr()), "ggq_dequantize_f16")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def gpu_quantize_q8_1(x):
+    L = ggqlib.hip()
+    batch, k = x.shape
+    q = torch.zeros(int(L.ggq_mmvq_scratch_bytes(k)) * batch, dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_quantize_q8_1(vp(x), ggqlib.dtype_code(x.dtype), vp(q), batch, k, stream_ptr()), "quantize")
+    torch.cuda.synchronize()
+    return q.cpu().numpy().reshape(batch, -1)
+
+
+def gpu_quantize_q8_1_mmq(x, t):
+    L = ggqlib.hip()
+    batch, k = x.shape
+    q = torch.zeros(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_quantize_q8_1_mmq(vp(x), ggqlib.dtype_code(x.dtype), vp(q), batch, k, int(t), stream_ptr()),
+                 "quantize_mmq")
+    torch.cuda.synchronize()
+    return q.cpu().numpy()
+
+
+def gpu_mmvq(w_np, x, t, n_rows):
+    L = ggqlib.hip()
+    k = x.shape[1]
+    w = dev_bytes(w_np)
+    y = torch.empty((1, n_rows), dtype=x.dtype, device="cuda")
+    scratch = torch.empty(int(L.ggq_mmvq_scratch_bytes(k)), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_mul_mat_vec_q(vp(w), vp(x), vp(y), int(t), ggqlib.dtype_code(x.dtype), k, n_rows,
+                                     vp(scratch), stream_ptr()), "ggq_mul_mat_vec_q")
+    torch.cuda.synchronize()
+    return y
+
+
+def gpu_mmq(w_np, x, t, n_rows):
+    L = ggqlib.hip()
+    batch, k = x.shape
+    w = dev_bytes(w_np)
+    y = torch.empty((batch, n_rows), dtype=x.dtype, device="cuda")
+    scratch = torch.empty(max(16, int(L.ggq_mmq_scratch_bytes(batch, k))), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_mul_mat_q(vp(w), vp(x), vp(y), int(t), ggqlib.dtype_code(x.dtype), batch, k, n_rows,
+                                 vp(scratch), stream_ptr()), "ggq_mul_mat_q")
+    torch.cuda.synchronize()
+    return y
+
+
+def same_nan(a, b):
+    """bit-level equality of fp16 arrays where any NaN equals any NaN"""
+    a = np.asarray(a, np.float16)
+    b = np.asarray(b, np.float16)
+    an, bn = np.isnan(a), np.isnan(b)
+    if not np.array_equal(an, bn):
+        return False
+    return np.array_equal(a.view(np.uint16)[~an], b.view(np.uint16)[~bn])
+
+
+DT_EPS = {torch.float32: 0.0, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
+
+
+def assert_fp_accumulate(y_gpu, y_ref, yabs, dtype, what=""):
+    """The north-star tolerance for the fp accumulate: 1e-3 relative.  y_ref is the oracle's
+    fp32 value before the cast to the output dtype; yabs = Σ|terms| scales the slack that fp32
+    re-association may cause when terms cancel (1e-5 of it), and one rounding step of the
+    output dtype is granted because both sides round a slightly different fp32 number."""
+    y = y_gpu.detach().float().cpu().numpy().reshape(y_ref.shape).astype(np.float64)
+    ref = y_ref.astype(np.float64)
+    tol = 1e-3 * np.abs(ref) + DT_EPS[dtype] * np.abs(ref) + 1e-5 * yabs.astype(np.float64) + 1e-30
+    bad = np.abs(y - ref) > tol
+    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside 1e-3 rel; worst "
+                           f"{np.max(np.abs(y - ref) / tol):.2f}x tol at {np.unravel_index(np.argmax(np.abs(y - ref) / tol), ref.shape)}")
