@@ -12,37 +12,47 @@
 // same factors (fp16 products for Q4_1/Q5_1, fp16 d8/s8 for need_sum formats, fp32 d8
 // otherwise, s8 — not d8·Σq8 — for the Q4_K/Q5_K min term); fp32 accumulation order ours.
 //
-// Structure (v1):
-//   workgroup = 256 threads = 4 waves = TB token-blocks x KS k-splits (TB·KS = 4);
-//   workgroup tile = 32 weight rows x 32·TB tokens; per outer step KS consecutive
-//   256-element K slabs are staged:
-//     * weights: global -> registers -> unpacked to signed int8 in LDS ([row][256+16 pad],
-//       the pad makes the 32-lane ds_read_b128 A-fragment reads conflict-free), per-(row,
-//       group) float scales in LDS laid out [group][row] so a lane fetches the 16 row
-//       scales of its accumulator registers with 4 broadcast ds_read_b128;
-//     * activations: the block_q8_1_mmq scratch is already MFMA-friendly (144-byte token
-//       pitch = 9 x 16 B, conflict-free for ds_read_b128), copied verbatim with 16-B accesses;
-//   wave (tb, ks): one v_mfma_i32_32x32x32_i8 per 32-element group (two 32x32x16 for the
-//   16-element-scale format Q6_K), lane = token, accumulator register = weight row, then
-//   acc[i] += (float(C[i]) · d8_lane) · sA[i]  (+ mA[i] · s8_lane).
-//   KS > 1 (small batches, HBM-bound): the k-split partials are reduced through LDS.
+// Structure (v2).  The kernel is VALU-bound, not MFMA- or HBM-bound: every (row, token,
+// 32-group) triple needs its own float scale, so the design minimises vector ops per triple.
+//   * workgroup = 512 threads = 8 waves = TBn token-blocks x (8/TBn) K-slices; workgroup tile
+//     ("unit") = 32 weight rows x 32·TBn tokens over all of K; one unit per workgroup, the
+//     hardware dispatcher balances the 2.7 units/CU of the headline shape;
+//   * K is walked in 256-element slabs; a slab's 8 groups are split over the K-slice waves, so
+//     each SIMD hosts two waves of the same tile (full VALU issue rate) and the K-slice partial
+//     sums are combined once per unit through LDS;
+//   * weights: global -> registers (prefetched two slabs ahead) -> unpacked to signed int8 in a
+//     double-buffered LDS tile ([row][256+16 pad]: conflict-free ds_read_b128 A fragments), with
+//     per-(group,row) float scales laid out [group][row] for broadcast ds_read_b128;
+//   * activations: block_q8_1_mmq scratch copied verbatim (16-B accesses, register prefetch two
+//     slabs ahead); its 144-byte token pitch is conflict-free for the B-fragment ds_read_b128;
+//   * per group: v_mfma_i32_32x32x32_i8 with the accumulator input preset to 0x4B400000, so the
+//     int32 result read as a float is 12582912 + C exactly — no v_cvt; for fp16 activation scales
+//     (need_sum formats) one fma(Df, d8, -12582912·d8) yields float(C)·d8 bit-exactly, a second
+//     fma applies the row scale: 2 vector ops per triple (3 with an fp32 d8);
+//   * Q4_K/Q5_K min term Σ m·s8 runs on the otherwise idle matrix pipe: one
+//     v_mfma_f32_32x32x2_f32 per group pair accumulates straight into the fp32 accumulators.
 #include "ggq_common.h"
 
 namespace ggq {
 
 constexpr int WROW = 272;  // LDS pitch of one unpacked int8 weight row (256 + 16)
+constexpr uint32_t MAGIC_I = 0x4B400000u;   // bits of 12582912.0f = 1.5 * 2^23
+constexpr float MAGIC_F = 12582912.0f;
 
 template <int T> struct MmqTraits {
-  static constexpr bool kquant = Fmt<T>::QK == 256;
   static constexpr bool need_sum = T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 || T == GGQ_TYPE_Q5_1 ||
                                    T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;  // mmq.cu:84-106
   static constexpr bool fp16_prod = T == GGQ_TYPE_Q4_1 || T == GGQ_TYPE_Q5_1;  // __hmul2(dm, ds8)
-  static constexpr bool has_min = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K || fp16_prod;
+  static constexpr bool mfma_min = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;   // min term on the matrix pipe
   static constexpr bool two_tiles = T == GGQ_TYPE_Q2_K;  // second int8 tile carries the mins
   static constexpr bool half_scales = T == GGQ_TYPE_Q6_K;  // scale per 16 elements -> K=16 MFMAs
   // float scale arrays per (group,row): 1 = sA; 2 = sA + (mA | sA1 | dmin)
-  static constexpr int n_scale = (has_min || two_tiles || half_scales) ? 2 : 1;
+  static constexpr int n_scale = (fp16_prod || mfma_min || two_tiles || half_scales) ? 2 : 1;
 };
+
+// int32 bits -> float, BY VALUE: __builtin_bit_cast applied directly to an ext-vector element
+// (bit_cast(float, v[i])) is miscompiled by this clang — it reads element 0 for every i.
+__device__ __forceinline__ float as_f32(int v) { return __builtin_bit_cast(float, v); }
 
 // (x - c) per byte for x in [0, 2c): exact, no inter-byte borrow
 __device__ __forceinline__ uint32_t sub_bytes(uint32_t x, uint32_t c4) {
@@ -52,333 +62,429 @@ __device__ __forceinline__ uint32_t spread4b(uint32_t x) {
   return ((x & 1) << 4) | ((x & 2) << 11) | ((x & 4) << 18) | ((x & 8) << 25);
 }
 
-// Unpack the 32-element group G (global index along K) of one weight row into 8 dwords of
-// signed int8 (w[]), an optional second tile (w2[], Q2_K mins) and its float scales.
+// Raw bytes of one 32-element weight group as loaded from global memory (prefetch registers);
+// only the members a format touches survive dead-code elimination.
+struct Raw {
+  u32x4_a2 q[5];
+  uint32_t s[4];
+};
+
 template <int T>
-__device__ __forceinline__ void unpack_group(const uint8_t* row, int G, uint32_t w[8], uint32_t w2[8],
-                                             float& s0, float& s1) {
-  s0 = 0.0f; s1 = 0.0f;
+__device__ __forceinline__ void load_raw(const uint8_t* row, int G, Raw& r) {
   if constexpr (T == GGQ_TYPE_Q4_0) {
     const uint8_t* b = row + (int64_t)G * 18;
-    const u32x4_a2 q = ld_u32x4(b + off::Q4_0_QS);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[i] = sub_bytes(q.v[i] & 0x0F0F0F0F, 0x08080808u);           // mmq.cuh:359
-      w[4 + i] = sub_bytes((q.v[i] >> 4) & 0x0F0F0F0F, 0x08080808u);
-    }
-    s0 = bits_h_f32(ld_u16(b));
+    r.q[0] = ld_u32x4(b + off::Q4_0_QS); r.s[0] = ld_u16(b);
   } else if constexpr (T == GGQ_TYPE_Q4_1) {
     const uint8_t* b = row + (int64_t)G * 20;
-    const u32x4_a2 q = ld_u32x4(b + off::Q4_1_QS);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { w[i] = q.v[i] & 0x0F0F0F0F; w[4 + i] = (q.v[i] >> 4) & 0x0F0F0F0F; }
-    const uint32_t dm = ld_u32(b);
-    s0 = bits_h_f32(dm & 0xFFFF); s1 = bits_h_f32(dm >> 16);
+    r.q[0] = ld_u32x4(b + off::Q4_1_QS); r.s[0] = ld_u32(b);
   } else if constexpr (T == GGQ_TYPE_Q5_0) {
     const uint8_t* b = row + (int64_t)G * 22;
-    const uint32_t qh = ld_u32(b + off::Q5_0_QH);
-    const u32x4_a2 q = ld_u32x4(b + off::Q5_0_QS);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[i] = sub_bytes((q.v[i] & 0x0F0F0F0F) | spread4b(qh >> (4 * i)), 0x10101010u);  // mmq.cuh:561
-      w[4 + i] = sub_bytes(((q.v[i] >> 4) & 0x0F0F0F0F) | spread4b(qh >> (16 + 4 * i)), 0x10101010u);
-    }
-    s0 = bits_h_f32(ld_u16(b));
+    r.q[0] = ld_u32x4(b + off::Q5_0_QS); r.s[0] = ld_u16(b); r.s[1] = ld_u32(b + off::Q5_0_QH);
   } else if constexpr (T == GGQ_TYPE_Q5_1) {
     const uint8_t* b = row + (int64_t)G * 24;
-    const uint32_t qh = ld_u32(b + off::Q5_1_QH);
-    const u32x4_a2 q = ld_u32x4(b + off::Q5_1_QS);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[i] = (q.v[i] & 0x0F0F0F0F) | spread4b(qh >> (4 * i));
-      w[4 + i] = ((q.v[i] >> 4) & 0x0F0F0F0F) | spread4b(qh >> (16 + 4 * i));
-    }
-    const uint32_t dm = ld_u32(b);
-    s0 = bits_h_f32(dm & 0xFFFF); s1 = bits_h_f32(dm >> 16);
+    r.q[0] = ld_u32x4(b + off::Q5_1_QS); r.s[0] = ld_u32(b); r.s[1] = ld_u32(b + off::Q5_1_QH);
   } else if constexpr (T == GGQ_TYPE_Q8_0) {
     const uint8_t* b = row + (int64_t)G * 34;
-    const u32x4_a2 q0 = ld_u32x4(b + off::Q8_0_QS), q1 = ld_u32x4(b + off::Q8_0_QS + 16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { w[i] = q0.v[i]; w[4 + i] = q1.v[i]; }
-    s0 = bits_h_f32(ld_u16(b));
+    r.q[0] = ld_u32x4(b + off::Q8_0_QS); r.q[1] = ld_u32x4(b + off::Q8_0_QS + 16); r.s[0] = ld_u16(b);
   } else if constexpr (T == GGQ_TYPE_Q2_K) {
-    const int ib = G >> 3, gl = G & 7, n = gl >> 2, j = gl & 3;
+    const int ib = G >> 3, gl = G & 7, n = gl >> 2;
     const uint8_t* b = row + (int64_t)ib * 84;
-    const u32x4_a2 q0 = ld_u32x4(b + off::Q2_K_QS + 32 * n), q1 = ld_u32x4(b + off::Q2_K_QS + 32 * n + 16);
-    const int sc0 = b[off::Q2_K_SC + 2 * gl], sc1 = b[off::Q2_K_SC + 2 * gl + 1];
+    r.q[0] = ld_u32x4(b + off::Q2_K_QS + 32 * n); r.q[1] = ld_u32x4(b + off::Q2_K_QS + 32 * n + 16);
+    r.s[0] = ld_u16(b + off::Q2_K_SC + 2 * gl); r.s[1] = ld_u32(b + off::Q2_K_D);
+  } else if constexpr (T == GGQ_TYPE_Q3_K) {
+    const int ib = G >> 3, gl = G & 7, n = gl >> 2;
+    const uint8_t* b = row + (int64_t)ib * 110;
+    r.q[0] = ld_u32x4(b + off::Q3_K_QS + 32 * n); r.q[1] = ld_u32x4(b + off::Q3_K_QS + 32 * n + 16);
+    r.q[2] = ld_u32x4(b + off::Q3_K_HM); r.q[3] = ld_u32x4(b + off::Q3_K_HM + 16);
+    const u32x3_a2 s = ld_u32x3(b + off::Q3_K_SC);
+    r.s[0] = s.v[0]; r.s[1] = s.v[1]; r.s[2] = s.v[2]; r.s[3] = ld_u16(b + off::Q3_K_D);
+  } else if constexpr (T == GGQ_TYPE_Q4_K) {
+    const int ib = G >> 3, il = (G & 7) >> 1;
+    const uint8_t* b = row + (int64_t)ib * 144;
+    r.q[0] = ld_u32x4(b + off::Q4_K_QS + 32 * il); r.q[1] = ld_u32x4(b + off::Q4_K_QS + 32 * il + 16);
+    r.q[2] = ld_u32x4(b);
+  } else if constexpr (T == GGQ_TYPE_Q5_K) {
+    const int ib = G >> 3, il = (G & 7) >> 1;
+    const uint8_t* b = row + (int64_t)ib * 176;
+    r.q[0] = ld_u32x4(b + off::Q5_K_QS + 32 * il); r.q[1] = ld_u32x4(b + off::Q5_K_QS + 32 * il + 16);
+    r.q[2] = ld_u32x4(b); r.q[3] = ld_u32x4(b + off::Q5_K_QH); r.q[4] = ld_u32x4(b + off::Q5_K_QH + 16);
+  } else if constexpr (T == GGQ_TYPE_Q6_K) {
+    const int ib = G >> 3, gl = G & 7, ip = gl >> 2, j = gl & 3;
+    const uint8_t* b = row + (int64_t)ib * 210;
+    const uint8_t* pl = b + off::Q6_K_QL + 64 * ip + 32 * (j & 1);
+    const uint8_t* ph = b + off::Q6_K_QH + 32 * ip;
+    r.q[0] = ld_u32x4(pl); r.q[1] = ld_u32x4(pl + 16); r.q[2] = ld_u32x4(ph); r.q[3] = ld_u32x4(ph + 16);
+    r.s[0] = ld_u16(b + off::Q6_K_D); r.s[1] = ld_u16(b + off::Q6_K_SC + 2 * gl);
+  }
+}
+
+// Raw -> 8 dwords of signed int8 (w[]), optional second tile (w2[], Q2_K mins), float scales.
+template <int T>
+__device__ __forceinline__ void unpack_raw(const Raw& r, int G, uint32_t w[8], uint32_t w2[8], float& s0, float& s1) {
+  s0 = 0.0f; s1 = 0.0f;
+  const int gl = G & 7;
+  if constexpr (T == GGQ_TYPE_Q4_0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = sub_bytes(r.q[0].v[i] & 0x0F0F0F0F, 0x08080808u);  // mmq.cuh:359
+      w[4 + i] = sub_bytes((r.q[0].v[i] >> 4) & 0x0F0F0F0F, 0x08080808u);
+    }
+    s0 = bits_h_f32(r.s[0]);
+  } else if constexpr (T == GGQ_TYPE_Q4_1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = r.q[0].v[i] & 0x0F0F0F0F; w[4 + i] = (r.q[0].v[i] >> 4) & 0x0F0F0F0F; }
+    s0 = bits_h_f32(r.s[0] & 0xFFFF); s1 = bits_h_f32(r.s[0] >> 16);
+  } else if constexpr (T == GGQ_TYPE_Q5_0) {
+    const uint32_t qh = r.s[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = sub_bytes((r.q[0].v[i] & 0x0F0F0F0F) | spread4b(qh >> (4 * i)), 0x10101010u);  // mmq.cuh:561
+      w[4 + i] = sub_bytes(((r.q[0].v[i] >> 4) & 0x0F0F0F0F) | spread4b(qh >> (16 + 4 * i)), 0x10101010u);
+    }
+    s0 = bits_h_f32(r.s[0]);
+  } else if constexpr (T == GGQ_TYPE_Q5_1) {
+    const uint32_t qh = r.s[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = (r.q[0].v[i] & 0x0F0F0F0F) | spread4b(qh >> (4 * i));
+      w[4 + i] = ((r.q[0].v[i] >> 4) & 0x0F0F0F0F) | spread4b(qh >> (16 + 4 * i));
+    }
+    s0 = bits_h_f32(r.s[0] & 0xFFFF); s1 = bits_h_f32(r.s[0] >> 16);
+  } else if constexpr (T == GGQ_TYPE_Q8_0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = r.q[0].v[i]; w[4 + i] = r.q[1].v[i]; }
+    s0 = bits_h_f32(r.s[0]);
+  } else if constexpr (T == GGQ_TYPE_Q2_K) {
+    const int j = gl & 3;
+    const int sc0 = r.s[0] & 0xFF, sc1 = (r.s[0] >> 8) & 0xFF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // bytes <= 3 * 15: the dword multiply cannot carry between bytes
-      w[i] = ((q0.v[i] >> (2 * j)) & 0x03030303u) * (uint32_t)(sc0 & 0xF);
-      w[4 + i] = ((q1.v[i] >> (2 * j)) & 0x03030303u) * (uint32_t)(sc1 & 0xF);
+      w[i] = ((r.q[0].v[i] >> (2 * j)) & 0x03030303u) * (uint32_t)(sc0 & 0xF);
+      w[4 + i] = ((r.q[1].v[i] >> (2 * j)) & 0x03030303u) * (uint32_t)(sc1 & 0xF);
       w2[i] = 0x01010101u * (uint32_t)(sc0 >> 4);
       w2[4 + i] = 0x01010101u * (uint32_t)(sc1 >> 4);
     }
-    const uint32_t dm = ld_u32(b + off::Q2_K_D);
-    s0 = bits_h_f32(dm & 0xFFFF); s1 = bits_h_f32(dm >> 16);
+    s0 = bits_h_f32(r.s[1] & 0xFFFF); s1 = bits_h_f32(r.s[1] >> 16);
   } else if constexpr (T == GGQ_TYPE_Q3_K) {
-    const int ib = G >> 3, gl = G & 7, n = gl >> 2, j = gl & 3;
-    const uint8_t* b = row + (int64_t)ib * 110;
-    const u32x4_a2 q0 = ld_u32x4(b + off::Q3_K_QS + 32 * n), q1 = ld_u32x4(b + off::Q3_K_QS + 32 * n + 16);
-    const u32x4_a2 h0 = ld_u32x4(b + off::Q3_K_HM), h1 = ld_u32x4(b + off::Q3_K_HM + 16);
-    const u32x3_a2 s = ld_u32x3(b + off::Q3_K_SC);
-    const int sc0 = q3k_scale(s.v[0], s.v[1], s.v[2], 2 * gl), sc1 = q3k_scale(s.v[0], s.v[1], s.v[2], 2 * gl + 1);
+    const int j = gl & 3;
+    const int sc0 = q3k_scale(r.s[0], r.s[1], r.s[2], 2 * gl), sc1 = q3k_scale(r.s[0], r.s[1], r.s[2], 2 * gl + 1);
     // tile holds -(q3 * sc) in [-128, 124] (q3*sc itself reaches +128); the sign goes into s0
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint32_t o0 = 0, o1 = 0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int v0 = (int)((q0.v[i] >> (8 * c + 2 * j)) & 3) - (((h0.v[i] >> (8 * c + gl)) & 1) ? 0 : 4);
-        const int v1 = (int)((q1.v[i] >> (8 * c + 2 * j)) & 3) - (((h1.v[i] >> (8 * c + gl)) & 1) ? 0 : 4);
+        const int v0 = (int)((r.q[0].v[i] >> (8 * c + 2 * j)) & 3) - (((r.q[2].v[i] >> (8 * c + gl)) & 1) ? 0 : 4);
+        const int v1 = (int)((r.q[1].v[i] >> (8 * c + 2 * j)) & 3) - (((r.q[3].v[i] >> (8 * c + gl)) & 1) ? 0 : 4);
         o0 |= (uint32_t)((-(v0 * sc0)) & 0xFF) << (8 * c);
         o1 |= (uint32_t)((-(v1 * sc1)) & 0xFF) << (8 * c);
       }
       w[i] = o0; w[4 + i] = o1;
     }
-    s0 = -bits_h_f32(ld_u16(b + off::Q3_K_D));
-  } else if constexpr (T == GGQ_TYPE_Q4_K) {
-    const int ib = G >> 3, gl = G & 7, il = gl >> 1, nib = gl & 1;
-    const uint8_t* b = row + (int64_t)ib * 144;
-    const u32x4_a2 hd = ld_u32x4(b);
-    const u32x4_a2 q0 = ld_u32x4(b + off::Q4_K_QS + 32 * il), q1 = ld_u32x4(b + off::Q4_K_QS + 32 * il + 16);
+    s0 = -bits_h_f32(r.s[3]);
+  } else if constexpr (T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K) {
+    const int nib = gl & 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      w[i] = (q0.v[i] >> (4 * nib)) & 0x0F0F0F0F;
-      w[4 + i] = (q1.v[i] >> (4 * nib)) & 0x0F0F0F0F;
+      w[i] = (r.q[0].v[i] >> (4 * nib)) & 0x0F0F0F0F;
+      w[4 + i] = (r.q[1].v[i] >> (4 * nib)) & 0x0F0F0F0F;
+      if constexpr (T == GGQ_TYPE_Q5_K) {
+        w[i] |= ((r.q[3].v[i] >> gl) & 0x01010101u) << 4;
+        w[4 + i] |= ((r.q[4].v[i] >> gl) & 0x01010101u) << 4;
+      }
     }
     int sc, mn;
-    k4_scale_min(hd.v[1], hd.v[2], hd.v[3], gl, sc, mn);
-    s0 = bits_h_f32(hd.v[0] & 0xFFFF) * (float)sc;
-    s1 = -(bits_h_f32(hd.v[0] >> 16) * (float)mn);
-  } else if constexpr (T == GGQ_TYPE_Q5_K) {
-    const int ib = G >> 3, gl = G & 7, il = gl >> 1, nib = gl & 1;
-    const uint8_t* b = row + (int64_t)ib * 176;
-    const u32x4_a2 hd = ld_u32x4(b);
-    const u32x4_a2 q0 = ld_u32x4(b + off::Q5_K_QS + 32 * il), q1 = ld_u32x4(b + off::Q5_K_QS + 32 * il + 16);
-    const u32x4_a2 h0 = ld_u32x4(b + off::Q5_K_QH), h1 = ld_u32x4(b + off::Q5_K_QH + 16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w[i] = ((q0.v[i] >> (4 * nib)) & 0x0F0F0F0F) | (((h0.v[i] >> gl) & 0x01010101u) << 4);
-      w[4 + i] = ((q1.v[i] >> (4 * nib)) & 0x0F0F0F0F) | (((h1.v[i] >> gl) & 0x01010101u) << 4);
-    }
-    int sc, mn;
-    k4_scale_min(hd.v[1], hd.v[2], hd.v[3], gl, sc, mn);
-    s0 = bits_h_f32(hd.v[0] & 0xFFFF) * (float)sc;
-    s1 = -(bits_h_f32(hd.v[0] >> 16) * (float)mn);
+    k4_scale_min(r.q[2].v[1], r.q[2].v[2], r.q[2].v[3], gl, sc, mn);
+    s0 = bits_h_f32(r.q[2].v[0] & 0xFFFF) * (float)sc;
+    s1 = -(bits_h_f32(r.q[2].v[0] >> 16) * (float)mn);
   } else if constexpr (T == GGQ_TYPE_Q6_K) {
-    const int ib = G >> 3, gl = G & 7, ip = gl >> 2, j = gl & 3;
-    const uint8_t* b = row + (int64_t)ib * 210;
-    const uint8_t* pl = b + off::Q6_K_QL + 64 * ip + 32 * (j & 1);
-    const uint8_t* ph = b + off::Q6_K_QH + 32 * ip;
-    const u32x4_a2 l0 = ld_u32x4(pl), l1 = ld_u32x4(pl + 16);
-    const u32x4_a2 h0 = ld_u32x4(ph), h1 = ld_u32x4(ph + 16);
+    const int j = gl & 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      w[i] = sub_bytes(((l0.v[i] >> (4 * (j >> 1))) & 0x0F0F0F0F) | (((h0.v[i] >> (2 * j)) & 0x03030303u) << 4), 0x20202020u);
-      w[4 + i] = sub_bytes(((l1.v[i] >> (4 * (j >> 1))) & 0x0F0F0F0F) | (((h1.v[i] >> (2 * j)) & 0x03030303u) << 4), 0x20202020u);
+      w[i] = sub_bytes(((r.q[0].v[i] >> (4 * (j >> 1))) & 0x0F0F0F0F) | (((r.q[2].v[i] >> (2 * j)) & 0x03030303u) << 4), 0x20202020u);
+      w[4 + i] = sub_bytes(((r.q[1].v[i] >> (4 * (j >> 1))) & 0x0F0F0F0F) | (((r.q[3].v[i] >> (2 * j)) & 0x03030303u) << 4), 0x20202020u);
     }
-    const float d = bits_h_f32(ld_u16(b + off::Q6_K_D));
-    s0 = d * (float)(int8_t)b[off::Q6_K_SC + 2 * gl];
-    s1 = d * (float)(int8_t)b[off::Q6_K_SC + 2 * gl + 1];
+    const float d = bits_h_f32(r.s[0]);
+    s0 = d * (float)(int8_t)(r.s[1] & 0xFF);
+    s1 = d * (float)(int8_t)((r.s[1] >> 8) & 0xFF);
   }
 }
 
-// LDS carve-up (bytes), all offsets multiples of 16
-template <int T, int TB, int KS> struct MmqLds {
-  static constexpr int TT = 32 * TB;                       // tokens per workgroup tile
-  static constexpr int W_TILE = 32 * WROW;                 // one int8 weight tile
-  static constexpr int W_BYTES = KS * W_TILE * (MmqTraits<T>::two_tiles ? 2 : 1);
-  static constexpr int S_BYTES = KS * MmqTraits<T>::n_scale * 8 * 32 * 4;
-  static constexpr int A_SLAB = 2 * TT * 144;              // one 256-element K slab of activations
-  static constexpr int A_BYTES = KS * A_SLAB;
+// LDS carve-up of one stage buffer (bytes); all offsets multiples of 16
+template <int T, int TBn> struct MmqLds {
+  static constexpr int TT = 32 * TBn;                      // tokens per workgroup tile
+  static constexpr int W_TILE = 32 * WROW;                 // one int8 weight tile (32 rows)
+  static constexpr int W_BYTES = W_TILE * (MmqTraits<T>::two_tiles ? 2 : 1);
+  static constexpr int S_BYTES = MmqTraits<T>::n_scale * 8 * 32 * 4;
+  static constexpr int A_BYTES = 2 * TT * 144;             // one 256-element K slab of activations
   static constexpr int W_OFF = 0;
   static constexpr int S_OFF = W_OFF + W_BYTES;
   static constexpr int A_OFF = S_OFF + S_BYTES;
-  static constexpr int TOTAL = A_OFF + A_BYTES;
-  static constexpr int RED_BYTES = KS > 1 ? 4 * 16 * 64 * 4 : 0;  // k-split reduction (aliases the tiles)
-  static constexpr int BYTES = TOTAL > RED_BYTES ? TOTAL : RED_BYTES;
+  static constexpr int STAGE = A_OFF + A_BYTES;
+  static constexpr int RED_BYTES = 8 * 16 * 64 * 4;        // K-slice reduction (aliases the stages)
+  static constexpr int BYTES = 2 * STAGE > RED_BYTES ? 2 * STAGE : RED_BYTES;
+  static constexpr int A_CHUNKS = 2 * TT * 9;              // 16-byte chunks of one activation slab
+  static constexpr int N_DMA = (A_CHUNKS + 255) / 256;     // LDS-DMA instructions per copy wave per slab
 };
 
-template <int T, int DT, int TB, int KS>
-__global__ void __launch_bounds__(256) mmq_kernel(const uint8_t* __restrict__ w,
+#define GGQ_LDS_BARRIER()                                   \
+  do {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+  } while (0)
+
+// Workgroup = 8 waves.  Waves 0-3 stage the weights (global -> registers one slab ahead ->
+// unpack -> LDS), waves 4-7 stream the activation slab with LDS-DMA (global_load_lds_dwordx4:
+// no VGPRs, no ds_write); all 8 waves compute.  Wave (tb, kq): 32-token block tb, K-slice kq.
+template <int T, int DT, int TBn>
+__global__ void __launch_bounds__(512) mmq_kernel(const uint8_t* __restrict__ w,
                                                   const uint8_t* __restrict__ q8,
                                                   void* __restrict__ y, int k, int n_rows, int batch,
-                                                  int64_t ldy) {
-  using L = MmqLds<T, TB, KS>;
+                                                  int64_t ldy, int n_tok_tiles) {
+  using L = MmqLds<T, TBn>;
   using TR = MmqTraits<T>;
   constexpr int TT = L::TT;
+  constexpr int KQ = 8 / TBn;   // K-slice waves per token block
+  constexpr int GPW = TBn;      // groups per wave per slab
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* lw = lds + L::W_OFF;
-  float* ls = (float*)(lds + L::S_OFF);
-  uint8_t* la = lds + L::A_OFF;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tb = wave % TB, ks = wave / TB;
-  const int n0 = blockIdx.x * 32;       // first weight row of the tile
-  const int t0 = blockIdx.y * TT;       // first token of the tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tb = wave % TBn, kq = wave / TBn;
+  const int unit = blockIdx.x;
+  const int n0 = (unit / n_tok_tiles) * 32;   // first weight row of the tile
+  const int t0 = (unit % n_tok_tiles) * TT;   // first token of the tile
   const int n_valid_tok = min(TT, batch - t0);
   const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
   const int n_groups = k / 32;          // 32-element groups along K
   const int n_slabs = (k + 255) / 256;  // 256-element K slabs
+  const bool w_wave = wave < 4;
+
+  // ---- weight staging role (waves 0-3): row sr, group sg of a slab ----
+  const int sr = (tid >> 3) & 31, sg = tid & 7;
+  const uint8_t* srow = w + (int64_t)min(n0 + sr, n_rows - 1) * row_bytes;
+  auto load_w = [&](Raw& R, int s) {
+    load_raw<T>(srow, min(min(s, n_slabs - 1) * 8 + sg, n_groups - 1), R);  // clamped, never predicated
+  };
+  auto write_w = [&](const Raw& R, int s, uint8_t* st) {
+    uint32_t wq[8], wq2[8];
+    float s0 = 0.0f, s1 = 0.0f;
+    unpack_raw<T>(R, s * 8 + sg, wq, wq2, s0, s1);
+    if (s * 8 + sg >= n_groups) {  // K tail of a legacy format: contributes nothing
+      s0 = 0.0f; s1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { wq[i] = 0; wq2[i] = 0; }
+    }
+    uint8_t* dst = st + L::W_OFF + sr * WROW + 32 * sg;
+    *(v4i*)dst = v4i{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
+    *(v4i*)(dst + 16) = v4i{(int)wq[4], (int)wq[5], (int)wq[6], (int)wq[7]};
+    if constexpr (TR::two_tiles) {
+      *(v4i*)(dst + L::W_TILE) = v4i{(int)wq2[0], (int)wq2[1], (int)wq2[2], (int)wq2[3]};
+      *(v4i*)(dst + L::W_TILE + 16) = v4i{(int)wq2[4], (int)wq2[5], (int)wq2[6], (int)wq2[7]};
+    }
+    float* sdst = (float*)(st + L::S_OFF) + sg * 32 + sr;
+    sdst[0] = s0;
+    if constexpr (TR::n_scale == 2) sdst[256] = s1;
+  };
+
+  // ---- activation streaming role (waves 4-7): DMA instruction j of a slab moves chunks 64j..64j+63 ----
+  int64_t dma_src[L::N_DMA];   // byte offset of this lane's chunk relative to slab 0, or -1
+#pragma unroll
+  for (int i = 0; i < L::N_DMA; ++i) {
+    const int j = i * 4 + (wave - 4);
+    const int c = 64 * j + lane;
+    const int kb = c >= TT * 9 ? 1 : 0;
+    int within = c - kb * TT * 9;
+    if (within >= n_valid_tok * 9) within = within % 9;  // token outside the batch: any valid bytes do
+    dma_src[i] = (w_wave || c >= L::A_CHUNKS) ? -1 : ((int64_t)kb * batch + t0) * 144 + 16 * within;
+  }
+  const int64_t slab_stride = (int64_t)2 * batch * 144;
+  auto dma_acts = [&](int s, uint8_t* st) {
+#pragma unroll
+    for (int i = 0; i < L::N_DMA; ++i) {
+      const int j = i * 4 + (wave - 4);
+      if (dma_src[i] >= 0)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(q8 + s * slab_stride + dma_src[i]),
+            (__attribute__((address_space(3))) void*)(st + L::A_OFF + 1024 * j), 16, 0, 0);
+    }
+  };
 
   v16f acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-
-  // staging role of this thread: weight row sr (0..31), group sg (0..7) of a slab
-  const int sr = tid >> 3, sg = tid & 7;
-  const uint8_t* srow = w + (int64_t)min(n0 + sr, n_rows - 1) * row_bytes;
-
-  for (int slab0 = 0; slab0 < n_slabs; slab0 += KS) {
-    // ---- stage weights (unpack) ----
+  v16i magic;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int G = (slab0 + s) * 8 + sg;
-      uint32_t wq[8], wq2[8];
-      float s0 = 0.0f, s1 = 0.0f;
-      if (G < n_groups) {
-        unpack_group<T>(srow, G, wq, wq2, s0, s1);
+  for (int i = 0; i < 16; ++i) magic[i] = (int)MAGIC_I;
+
+  const int r = lane & 31, h = lane >> 5;
+  const int tl = tb * 32 + r;  // token within the tile
+
+  auto compute = [&](const uint8_t* st) {
+    const uint8_t* wt = st + L::W_OFF;
+    const float* sc = (const float*)(st + L::S_OFF);
+    const uint8_t* at = st + L::A_OFF;
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+      const int g = kq * GPW + j;
+      const uint8_t* ablk = at + ((g >> 2) * TT + tl) * 144;
+      const uint32_t dsw = *(const uint32_t*)(ablk + 4 * (g & 3));
+      float bs, bm = 0.0f;
+      if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
+      else bs = as_f32((int)dsw);
+      const float nmbs = -(MAGIC_F * bs);  // exact when bs is an fp16 value (need_sum formats)
+
+      v16i c0, c1 = magic;
+      if constexpr (TR::half_scales) {
+        const long a0 = *(const long*)(wt + r * WROW + 32 * g + 8 * h);
+        const long a1 = *(const long*)(wt + r * WROW + 32 * g + 16 + 8 * h);
+        const long b0 = *(const long*)(ablk + 16 + 32 * (g & 3) + 8 * h);
+        const long b1 = *(const long*)(ablk + 16 + 32 * (g & 3) + 16 + 8 * h);
+        c0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a0, b0, magic, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1, b1, magic, 0, 0, 0);
       } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wq[i] = 0; wq2[i] = 0; }
+        const v4i a = *(const v4i*)(wt + r * WROW + 32 * g + 16 * h);
+        const v4i b = *(const v4i*)(ablk + 16 + 32 * (g & 3) + 16 * h);
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, magic, 0, 0, 0);
+        if constexpr (TR::two_tiles) {
+          const v4i a2 = *(const v4i*)(wt + L::W_TILE + r * WROW + 32 * g + 16 * h);
+          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b, magic, 0, 0, 0);
+        }
       }
-      uint8_t* dst = lw + s * L::W_TILE + sr * WROW + 32 * sg;
-      *(v4i*)dst = v4i{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
-      *(v4i*)(dst + 16) = v4i{(int)wq[4], (int)wq[5], (int)wq[6], (int)wq[7]};
-      if constexpr (TR::two_tiles) {
-        uint8_t* dst2 = dst + KS * L::W_TILE;
-        *(v4i*)dst2 = v4i{(int)wq2[0], (int)wq2[1], (int)wq2[2], (int)wq2[3]};
-        *(v4i*)(dst2 + 16) = v4i{(int)wq2[4], (int)wq2[5], (int)wq2[6], (int)wq2[7]};
+      if constexpr (TR::mfma_min) {
+        // Σ_g (-dmin·m)[row,g] · s8[token,g] for the group pair (g & ~1, g | 1): K = 2 outer products
+        if ((j & 1) == 0) {
+          const int gp = GPW >= 2 ? g + h : g;
+          const float am = (GPW >= 2 || h == 0) ? sc[256 + gp * 32 + r] : 0.0f;
+          const uint32_t dsp = *(const uint32_t*)(at + ((gp >> 2) * TT + tl) * 144 + 4 * (gp & 3));
+          const float bmp = (GPW >= 2 || h == 0) ? bits_h_f32(dsp >> 16) : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bmp, acc, 0, 0, 0);
+        }
       }
-      float* sdst = ls + (s * TR::n_scale) * 256 + sg * 32 + sr;
-      sdst[0] = s0;
-      if constexpr (TR::n_scale == 2) sdst[256] = s1;
-    }
-    // ---- stage activations: KS slabs x 2 blocks x n_valid_tok x 144 B, contiguous per block ----
+      // accumulator register i <-> tile row (i&3) + 8(i>>2) + 4h : 4 runs of 4 consecutive rows
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+      for (int qd = 0; qd < 4; ++qd) {
+        const v4f sa = *(const v4f*)(sc + g * 32 + 8 * qd + 4 * h);
+        v4f sb = {0, 0, 0, 0};
+        if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb = *(const v4f*)(sc + 256 + g * 32 + 8 * qd + 4 * h);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int64_t kblock = (int64_t)(slab0 + s) * 2 + kb;
-        const uint8_t* src = q8 + (kblock * batch + t0) * 144;
-        uint8_t* dst = la + s * L::A_SLAB + kb * TT * 144;
-        // scratch holds padded/128 >= 2*n_slabs blocks per token: every kblock of a real slab exists
-        const int n16 = (slab0 + s < n_slabs) ? n_valid_tok * 9 : 0;  // 144 B = 9 x 16 B per token
-        for (int i = tid; i < n16; i += 256) *(v4i*)(dst + 16 * i) = *(const v4i*)(src + 16 * i);
-      }
-    }
-    __syncthreads();
-
-    // ---- compute: wave (tb, ks) on slab slab0+ks ----
-    if (slab0 + ks < n_slabs) {
-      const uint8_t* wt = lw + ks * L::W_TILE;
-      const float* st = ls + (ks * TR::n_scale) * 256;
-      const uint8_t* at = la + ks * L::A_SLAB;
-      const int r = lane & 31, h = lane >> 5;
-      const int tl = tb * 32 + r;  // token within the tile
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const uint8_t* ablk = at + ((g >> 2) * TT + tl) * 144;
-        const uint32_t dsw = *(const uint32_t*)(ablk + 4 * (g & 3));
-        float bs, bm = 0.0f;
-        if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
-        else bs = __builtin_bit_cast(float, dsw);
-
-        v16i c0, c1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { c0[i] = 0; c1[i] = 0; }
-        if constexpr (TR::half_scales) {
-          const long a0 = *(const long*)(wt + r * WROW + 32 * g + 8 * h);
-          const long a1 = *(const long*)(wt + r * WROW + 32 * g + 16 + 8 * h);
-          const long b0 = *(const long*)(ablk + 16 + 32 * (g & 3) + 8 * h);
-          const long b1 = *(const long*)(ablk + 16 + 32 * (g & 3) + 16 + 8 * h);
-          c0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a0, b0, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1, b1, c1, 0, 0, 0);
-        } else {
-          const v4i a = *(const v4i*)(wt + r * WROW + 32 * g + 16 * h);
-          const v4i b = *(const v4i*)(ablk + 16 + 32 * (g & 3) + 16 * h);
-          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
-          if constexpr (TR::two_tiles) {
-            const v4i a2 = *(const v4i*)(wt + KS * L::W_TILE + r * WROW + 32 * g + 16 * h);
-            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b, c1, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * qd + e;
+          const float df0 = as_f32(c0[i]);  // = 12582912 + C exactly
+          // explicit fma + -ffp-contract=off: every accumulator register sees the same
+          // instruction sequence, so a row's result does not depend on its position in the tile
+          if constexpr (TR::fp16_prod) {  // Q4_1/Q5_1, mmq.cuh:527-529 / :840-842
+            const float lo = (float)((_Float16)sa[e] * (_Float16)bs);
+            const float hi = (float)((_Float16)sb[e] * (_Float16)bm);
+            acc[i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
+          } else if constexpr (TR::two_tiles) {  // Q2_K: d8 (dall·Σsc q q8 − dmin·Σ m q8), mmq.cuh:47
+            const float df1 = as_f32(c1[i]);
+            acc[i] = __builtin_fmaf(bs, __builtin_fmaf(sa[e], df0 - MAGIC_F, -(sb[e] * (df1 - MAGIC_F))), acc[i]);
+          } else if constexpr (TR::half_scales) {  // Q6_K (fp32 d8): mmq.cuh:1726-1732
+            const float df1 = as_f32(c1[i]);
+            acc[i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sa[e], acc[i]);
+            acc[i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sb[e], acc[i]);
+          } else if constexpr (TR::need_sum) {  // Q4_0, Q4_K, Q5_K (fp16 d8): float(C)·d8 in one exact fma
+            acc[i] = __builtin_fmaf(__builtin_fmaf(df0, bs, nmbs), sa[e], acc[i]);
+          } else {  // Q5_0 / Q8_0 / Q3_K (fp32 d8): d_w d8 C
+            acc[i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sa[e], acc[i]);
           }
         }
-        // accumulator register i <-> tile row (i&3) + 8(i>>2) + 4h : 4 runs of 4 consecutive rows
+      }
+    }
+  };
+
+  // ---- K loop: slab s in stage (s&1); during compute(s) the next slab is written / DMA'd into the
+  //      other stage, whose previous contents (slab s-1) every wave finished before the last barrier ----
+  uint8_t* st0 = lds;
+  uint8_t* st1 = lds + L::STAGE;
+  Raw R;
+  if (w_wave) {
+    load_w(R, 0);
+    write_w(R, 0, st0);
+    load_w(R, 1);
+  } else {
+    dma_acts(0, st0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  GGQ_LDS_BARRIER();
+  for (int s = 0; s < n_slabs; ++s) {
+    uint8_t* cur = (s & 1) ? st1 : st0;
+    uint8_t* nxt = (s & 1) ? st0 : st1;
+    const bool more = s + 1 < n_slabs;
+    if (w_wave) {
+      if (more) write_w(R, s + 1, nxt);   // registers were loaded during the previous slab
+      load_w(R, s + 2);
+    } else if (more) {
+      dma_acts(s + 1, nxt);
+    }
+    compute(cur);
+    if (!w_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GGQ_LDS_BARRIER();
+  }
+
+  // ---- K-slice reduction through LDS ----
+  if constexpr (KQ > 1) {
+    float* red = (float*)lds;  // [wave][16][64]; the stage buffers are dead after the last barrier
+    if (kq > 0) {
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const v4f sa = *(const v4f*)(st + g * 32 + 8 * qd + 4 * h);
-          v4f sb = {0, 0, 0, 0};
-          if constexpr (TR::n_scale == 2) sb = *(const v4f*)(st + 256 + g * 32 + 8 * qd + 4 * h);
+      for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+    }
+    GGQ_LDS_BARRIER();
+    if (kq == 0) {
+#pragma unroll
+      for (int s = 1; s < KQ; ++s)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += red[((s * TBn + tb) * 16 + i) * 64 + lane];
+    }
+  }
+
+  // ---- write back: lane = token, register i = row (i&3) + 8(i>>2) + 4h ----
+  if (kq == 0) {
+    const int t = t0 + tl;
+    if (t < batch) {
+      const bool vec_ok = DT != GGQ_F32 && (ldy & 3) == 0 && ((uintptr_t)y & 7) == 0 && n0 + 32 <= n_rows;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int row = n0 + 8 * qd + 4 * h;
+        if (vec_ok) {
+          uint16_t hv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int i = 4 * qd + e;
-            // explicit fmaf + -ffp-contract=off: every accumulator register sees the same
-            // instruction sequence, so a row's result does not depend on its position in the tile
-            if constexpr (TR::fp16_prod) {  // mmq.cuh:527-529 / :840-842
-              const float lo = (float)((_Float16)sa[e] * (_Float16)bs);
-              const float hi = (float)((_Float16)sb[e] * (_Float16)bm);
-              acc[i] += __builtin_fmaf(lo, (float)c0[i], hi);
-            } else if constexpr (TR::two_tiles) {  // Q2_K: d8 (dall·Σsc q q8 − dmin·Σ m q8), mmq.cuh:47
-              acc[i] = __builtin_fmaf(bs, __builtin_fmaf(sa[e], (float)c0[i], -(sb[e] * (float)c1[i])), acc[i]);
-            } else if constexpr (TR::half_scales) {  // Q6_K: mmq.cuh:1726-1732
-              acc[i] = __builtin_fmaf((float)c0[i] * bs, sa[e], acc[i]);
-              acc[i] = __builtin_fmaf((float)c1[i] * bs, sb[e], acc[i]);
-            } else if constexpr (TR::has_min) {  // Q4_K/Q5_K: dall sc C d8 − dmin m s8, mmq.cuh:1352-1359
-              acc[i] = __builtin_fmaf((float)c0[i] * bs, sa[e], acc[i]);
-              acc[i] = __builtin_fmaf(sb[e], bm, acc[i]);
-            } else {  // Q4_0 / Q5_0 / Q8_0 / Q3_K: d_w d8 C
-              acc[i] = __builtin_fmaf((float)c0[i] * bs, sa[e], acc[i]);
-            }
+            if (DT == GGQ_F16) hv[e] = __builtin_bit_cast(uint16_t, (_Float16)acc[4 * qd + e]);
+            else hv[e] = Elem<GGQ_BF16>::cvt(acc[4 * qd + e]);
           }
+          uint2 pk;
+          pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+          pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+          *(uint2*)((uint16_t*)y + (int64_t)t * ldy + row) = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (row + e < n_rows) Elem<DT>::st(y, (int64_t)t * ldy + row + e, acc[4 * qd + e]);
         }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- k-split reduction through LDS ----
-  if constexpr (KS > 1) {
-    float* red = (float*)lds;  // [wave][16][64]
-#pragma unroll
-    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
-    __syncthreads();
-    if (ks == 0) {
-#pragma unroll
-      for (int s = 1; s < KS; ++s)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += red[((s * TB + tb) * 16 + i) * 64 + lane];
-    }
-  }
-
-  // ---- write back: lane = token, register i = row ----
-  if (ks == 0) {
-    const int t = t0 + tb * 32 + (lane & 31);
-    const int h = lane >> 5;
-    if (t < batch) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = n0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (row < n_rows) Elem<DT>::st(y, (int64_t)t * ldy + row, acc[i]);
       }
     }
   }
 }
 
-template <int T, int DT, int TB, int KS>
+template <int T, int DT, int TBn>
 static int launch_mmq_cfg(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                           int64_t ldy, hipStream_t s) {
-  using L = MmqLds<T, TB, KS>;
-  auto kern = mmq_kernel<T, DT, TB, KS>;
+  using L = MmqLds<T, TBn>;
+  auto kern = mmq_kernel<T, DT, TBn>;
   static bool attr_set = false;  // one-time per instantiation (the reference does it on every call)
   if (L::BYTES > 64 * 1024 && !attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES) != hipSuccess)
       return GGQ_ERR_LAUNCH;
     attr_set = true;
   }
-  const dim3 grid((unsigned)((n + 31) / 32), (unsigned)((batch + L::TT - 1) / L::TT));
-  if (grid.y > 65535) return GGQ_ERR_SHAPE;
-  hipLaunchKernelGGL(kern, grid, dim3(256), L::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y,
-                     (int)k, (int)n, (int)batch, ldy);
+  const int64_t n_tok_tiles = (batch + L::TT - 1) / L::TT;
+  const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
+  if (n_units > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_units), dim3(512), L::BYTES, s, (const uint8_t*)w,
+                     (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy, (int)n_tok_tiles);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }
@@ -386,9 +492,12 @@ static int launch_mmq_cfg(const void* w, const void* q8, void* y, int64_t batch,
 template <int T, int DT>
 static int launch_mmq_t(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                         int64_t ldy, hipStream_t s) {
-  if (batch <= 32) return launch_mmq_cfg<T, DT, 1, 4>(w, q8, y, batch, k, n, ldy, s);
-  if (batch <= 64) return launch_mmq_cfg<T, DT, 2, 2>(w, q8, y, batch, k, n, ldy, s);
-  return launch_mmq_cfg<T, DT, 4, 1>(w, q8, y, batch, k, n, ldy, s);
+  if (batch <= 32) return launch_mmq_cfg<T, DT, 1>(w, q8, y, batch, k, n, ldy, s);
+  // 64-token units give the dispatcher 2x more, smaller units to balance (688 vs 344 at the headline
+  // shape); 128-token units halve the weight re-staging once there are plenty of units anyway
+  const int64_t units128 = ((n + 31) / 32) * ((batch + 127) / 128);
+  if (batch <= 64 || units128 < 2048) return launch_mmq_cfg<T, DT, 2>(w, q8, y, batch, k, n, ldy, s);
+  return launch_mmq_cfg<T, DT, 4>(w, q8, y, batch, k, n, ldy, s);
 }
 
 template <int T>
