@@ -211,7 +211,7 @@ def main():
         # rank-local slab + all-gather on a side stream, double buffered
         comm = torch.cuda.Stream(device=dev)
         ys = [torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world, BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
         done = [None, None]
 
         def step(i):

@@ -48,6 +48,8 @@ template <int T> struct MmqTraits {
   static constexpr bool half_scales = T == GGQ_TYPE_Q6_K;  // scale per 16 elements -> K=16 MFMAs
   // float scale arrays per (group,row): 1 = sA; 2 = sA + (mA | sA1 | dmin)
   static constexpr int n_scale = (fp16_prod || mfma_min || two_tiles || half_scales) ? 2 : 1;
+  // one int32 result tile per group: fits 128 VGPRs, so two workgroups share a CU (4 waves/SIMD)
+  static constexpr bool light = !(fp16_prod || two_tiles || half_scales);
 };
 
 // int32 bits -> float, BY VALUE: __builtin_bit_cast applied directly to an ext-vector element
@@ -238,7 +240,7 @@ template <int T, int TBn> struct MmqLds {
 // unpack -> LDS), waves 4-7 stream the activation slab with LDS-DMA (global_load_lds_dwordx4:
 // no VGPRs, no ds_write); all 8 waves compute.  Wave (tb, kq): 32-token block tb, K-slice kq.
 template <int T, int DT, int TBn>
-__global__ void __launch_bounds__(512) mmq_kernel(const uint8_t* __restrict__ w,
+__global__ void __launch_bounds__(512, MmqTraits<T>::light && TBn <= 2 ? 4 : 2) mmq_kernel(const uint8_t* __restrict__ w,
                                                   const uint8_t* __restrict__ q8,
                                                   void* __restrict__ y, int k, int n_rows, int batch,
                                                   int64_t ldy, int n_tok_tiles) {
@@ -496,7 +498,7 @@ static int launch_mmq_t(const void* w, const void* q8, void* y, int64_t batch, i
   // 64-token units give the dispatcher 2x more, smaller units to balance (688 vs 344 at the headline
   // shape); 128-token units halve the weight re-staging once there are plenty of units anyway
   const int64_t units128 = ((n + 31) / 32) * ((batch + 127) / 128);
-  if (batch <= 64 || units128 < 2048) return launch_mmq_cfg<T, DT, 2>(w, q8, y, batch, k, n, ldy, s);
+  if (batch <= 64 || units128 < 2048 || !MmqTraits<T>::light) return launch_mmq_cfg<T, DT, 2>(w, q8, y, batch, k, n, ldy, s);
   return launch_mmq_cfg<T, DT, 4>(w, q8, y, batch, k, n, ldy, s);
 }
 

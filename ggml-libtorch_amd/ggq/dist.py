@@ -29,8 +29,8 @@ def gather_slabs(y_local: torch.Tensor, n_rows: int, group=None, out: Optional[t
     """All-gather the per-rank [batch, rows_r] slabs into [batch, n_rows].
 
     Equal shards use one all_gather_into_tensor into a [P, batch, N/P] buffer that is
-    returned as a [batch, N] *view* (permute, no copy when P == 1); ragged shards fall
-    back to all_gather with per-rank tensors.  Returns (y_full, work_or_None)."""
+    returned as [batch, N]; ragged shards are zero-padded to the widest shard first.
+    Returns (y_full, work_or_None) — with async_op the raw [P, batch, rows] buffer is returned."""
     world = dist.get_world_size(group)
     batch = y_local.shape[0]
     if world == 1:
@@ -38,17 +38,27 @@ def gather_slabs(y_local: torch.Tensor, n_rows: int, group=None, out: Optional[t
     if n_rows % world == 0:
         rows = n_rows // world
         assert y_local.shape == (batch, rows)
-        buf = out if out is not None else torch.empty((world, batch, rows), dtype=y_local.dtype,
+        # concatenated-along-dim-0 form [P*batch, rows]: accepted by both RCCL and gloo
+        buf = out if out is not None else torch.empty((world * batch, rows), dtype=y_local.dtype,
                                                       device=y_local.device)
-        work = dist.all_gather_into_tensor(buf, y_local.contiguous(), group=group, async_op=async_op)
-        return buf.permute(1, 0, 2).reshape(batch, n_rows) if not async_op else buf, work
+        work = dist.all_gather_into_tensor(buf.view(world * batch, rows), y_local.contiguous(), group=group,
+                                           async_op=async_op)
+        buf3 = buf.view(world, batch, rows)
+        return (buf3.permute(1, 0, 2).reshape(batch, n_rows) if not async_op else buf3), work
+    # ragged shards: collectives need equal contributions -> pad every slab to the widest shard,
+    # gather, then drop the padding columns
+    rows_max = -(-n_rows // world)
+    padded = torch.zeros((batch, rows_max), dtype=y_local.dtype, device=y_local.device)
+    padded[:, :y_local.shape[1]] = y_local
+    buf = torch.empty((world * batch, rows_max), dtype=y_local.dtype, device=y_local.device)
+    work = dist.all_gather_into_tensor(buf, padded, group=group, async_op=async_op)
+    if async_op:
+        return buf.view(world, batch, rows_max), work
+    buf3 = buf.view(world, batch, rows_max)
     parts = []
     for r in range(world):
         s, e = shard_rows(n_rows, world, r)
-        parts.append(torch.empty((batch, e - s), dtype=y_local.dtype, device=y_local.device))
-    work = dist.all_gather(parts, y_local.contiguous(), group=group, async_op=async_op)
-    if async_op:
-        return parts, work
+        parts.append(buf3[r, :, :e - s])
     return torch.cat(parts, dim=1), None
 
 
