@@ -327,8 +327,9 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
   constexpr int ROWS = 2;
   const size_t lds = mmvq_lds_bytes(k);
   if (lds > 160 * 1024) return GGQ_ERR_SHAPE;
-  // ~2-4 workgroups per CU (256 CUs x 4 waves): rows_per_wave = n / 2048, even, in [2, 16]
-  int rpw = (int)(n / 2048);
+  // many short-lived waves keep more weight bytes in flight (measured: 2 rows per wave beats
+  // 4-8 at N = 11008); rows_per_wave = n / 8192, even, in [2, 16]
+  int rpw = (int)(n / 8192);
   rpw = rpw < ROWS ? ROWS : (rpw > 16 ? 16 : rpw);
   rpw = (rpw + ROWS - 1) / ROWS * ROWS;
   const int64_t waves = (n + rpw - 1) / rpw;
