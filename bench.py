@@ -273,7 +273,7 @@ def main():
 
         us_med, us_min = time_launches(mmq_only, 200, use_graph=not args.eager)
         achieved = bytes_per_step / (us_med * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "mmq_kernel<Q4_K, f16, TB=4, KS=1>",
+        out["roofline"] = {"bound": "hbm", "kernel": "ggq::mmq_kernel<Q4_K, f16, TBn=2> (32 rows x 64 tokens per workgroup)",
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                            "avg_launch_us": round(us_med, 3), "min_launch_us": round(us_min, 3),
