@@ -273,9 +273,14 @@ def main():
 
         us_med, us_min = time_launches(mmq_only, 200, use_graph=not args.eager)
         achieved = bytes_per_step / (us_med * 1e-6) / 1e9
+        traffic = None  # PMC-derived HBM bytes per launch, measured offline with rocprofv3 (profiles/)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["mmq_q4_k_batch128"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": "ggq::mmq_kernel<Q4_K, f16, TBn=2> (32 rows x 64 tokens per workgroup)",
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "avg_launch_us": round(us_med, 3), "min_launch_us": round(us_min, 3),
                            "algorithmic_bytes_per_launch": bytes_per_step,
                            "int8_mfma_TOPs": round(2.0 * BATCH * N_DIM * K_DIM / (us_med * 1e-6) / 1e12, 2),
