@@ -778,9 +778,180 @@ static int launch_mmq_cfg(const void* w, const void* q8, void* y, int64_t batch,
   return GGQ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-batch kernel (batch <= 16): HBM-bound, so no MFMA tiles — the weight stream is read
+// exactly once with coalesced per-lane block loads (lane = one 32-element group of a row,
+// consecutive lanes = consecutive blocks), each group is unpacked once with the same unpack_raw
+// as the MFMA path (identical integer operands and scales: MMQ canon) and dotted against every
+// token with v_dot4_i32_i8; the block_q8_1_mmq activations of all tokens sit in LDS.
+// A 64-lane "folding" butterfly reduces the NTOK per-lane sums with NTOK/2+... shuffles.
+// ---------------------------------------------------------------------------------------------
+template <int T, int DT, int NTOK>
+__global__ void __launch_bounds__(1024) mmq_small_kernel(const uint8_t* __restrict__ w,
+                                                        const uint8_t* __restrict__ q8,
+                                                        void* __restrict__ y, int k, int n_rows, int batch,
+                                                        int64_t ldy, int rows_per_wave) {
+  using TR = MmqTraits<T>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int n_groups = k / 32;
+  constexpr int GP = 48;  // LDS pitch of one 32-byte activation group: conflict-free 64-lane ds_read_b128
+  int8_t* xq = (int8_t*)lds;                                  // [NTOK][n_groups][GP]
+  uint32_t* xds = (uint32_t*)(lds + (size_t)NTOK * n_groups * GP);  // [NTOK][n_groups] (d,s) / float d words
+
+  // ---- stage activations: block (kb, t) of 144 B -> xq[t][4 kb + i][..], xds[t][4 kb + i] ----
+  const int n_kb = (k + 127) / 128;
+  for (int c = threadIdx.x; c < n_kb * NTOK * 9; c += 1024) {
+    const int blk = c / 9, part = c - blk * 9;
+    const int kb = blk / NTOK, t = blk - kb * NTOK;
+    const int ts = min(t, batch - 1);  // tokens beyond the batch: duplicate (results discarded)
+    const v4i v = *(const v4i*)(q8 + ((int64_t)kb * batch + ts) * 144 + 16 * part);
+    if (part == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * kb + i < n_groups) xds[t * n_groups + 4 * kb + i] = (uint32_t)v[i];
+    } else {
+      const int g = 4 * kb + ((part - 1) >> 1);
+      if (g < n_groups) *(v4i*)(xq + ((size_t)t * n_groups + g) * GP + 16 * ((part - 1) & 1)) = v;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 16 + (threadIdx.x >> 6);
+  const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
+  const int row_end = min(n_rows, (wave + 1) * rows_per_wave);
+
+  // steps enumerate (row, 64-group chunk).  (Loading step st+1's bytes ahead of step st's dot products
+  // was measured slower: the extra 24 live registers cost more than the exposed latency.)
+  const int nsteps = (n_groups + 63) / 64;
+  const int row_begin = wave * rows_per_wave;
+  const int total = max(0, row_end - row_begin) * nsteps;
+  auto fetch = [&](Raw& R, int st) {
+    const int row = row_begin + st / nsteps;
+    const int G = min(lane + 64 * (st % nsteps), n_groups - 1);  // clamped, never predicated
+    load_raw<T>(w + row * row_bytes, G, R);
+  };
+  Raw Rcur;
+  float acc[NTOK];
+#pragma unroll
+  for (int t = 0; t < NTOK; ++t) acc[t] = 0.0f;
+  for (int st = 0; st < total; ++st) {
+    const int row = row_begin + st / nsteps;
+    const int us = st % nsteps;
+    const int G = lane + 64 * us;
+    fetch(Rcur, st);
+    if (G < n_groups) {
+      uint32_t wq[8], wq2[8];
+      float s0, s1;
+      unpack_raw<T>(Rcur, G, wq, wq2, s0, s1);
+#pragma unroll
+      for (int t = 0; t < NTOK; ++t) {
+        const v4i a0 = *(const v4i*)(xq + ((size_t)t * n_groups + G) * GP);
+        const v4i a1 = *(const v4i*)(xq + ((size_t)t * n_groups + G) * GP + 16);
+        const uint32_t dsw = xds[t * n_groups + G];
+        float bs, bm = 0.0f;
+        if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
+        else bs = as_f32((int)dsw);
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c0 = __builtin_amdgcn_sdot4((int)wq[i], a0[i], c0, false);
+          if constexpr (TR::half_scales) c1 = __builtin_amdgcn_sdot4((int)wq[4 + i], a1[i], c1, false);
+          else c0 = __builtin_amdgcn_sdot4((int)wq[4 + i], a1[i], c0, false);
+          if constexpr (TR::two_tiles) {
+            c1 = __builtin_amdgcn_sdot4((int)wq2[i], a0[i], c1, false);
+            c1 = __builtin_amdgcn_sdot4((int)wq2[4 + i], a1[i], c1, false);
+          }
+        }
+        // same float combinations as the MFMA kernels (explicit FMAs, -ffp-contract=off)
+        if constexpr (TR::fp16_prod) {
+          const float lo = (float)((_Float16)s0 * (_Float16)bs);
+          const float hi = (float)((_Float16)s1 * (_Float16)bm);
+          acc[t] += __builtin_fmaf(lo, (float)c0, hi);
+        } else if constexpr (TR::two_tiles) {
+          acc[t] = __builtin_fmaf(bs, __builtin_fmaf(s0, (float)c0, -(s1 * (float)c1)), acc[t]);
+        } else if constexpr (TR::half_scales) {
+          acc[t] = __builtin_fmaf((float)c0 * bs, s0, acc[t]);
+          acc[t] = __builtin_fmaf((float)c1 * bs, s1, acc[t]);
+        } else if constexpr (TR::mfma_min) {
+          acc[t] = __builtin_fmaf((float)c0 * bs, s0, acc[t]);
+          acc[t] = __builtin_fmaf(s1, bm, acc[t]);
+        } else {
+          acc[t] = __builtin_fmaf((float)c0 * bs, s0, acc[t]);
+        }
+      }
+    }
+    if (us != nsteps - 1) continue;
+    // ---- folding butterfly: after the steps with n > 1 values, lane l holds token (l >> shift) ----
+    float v[NTOK];
+#pragma unroll
+    for (int t = 0; t < NTOK; ++t) v[t] = acc[t];
+    int n = NTOK, m = 32;
+#pragma unroll
+    for (; n > 1; n >>= 1, m >>= 1) {
+      const bool upper = (lane & m) != 0;
+#pragma unroll
+      for (int j = 0; j < NTOK / 2; ++j) {
+        if (j < n / 2) {
+          const float keep = upper ? v[j + n / 2] : v[j];
+          const float give = upper ? v[j] : v[j + n / 2];
+          v[j] = keep + __shfl_xor(give, m, 64);
+        }
+      }
+    }
+    float r = v[0];
+#pragma unroll
+    for (; m > 0; m >>= 1) r += __shfl_xor(r, m, 64);
+    // lanes with equal (lane / (64 / NTOK)) now hold the total of token  bitreverse-free index:
+    // the token kept at each fold is selected by the lane bit, MSB first => token = lane / (64 / NTOK)
+    constexpr int LPT = 64 / NTOK;
+    const int t = lane / LPT;
+    if ((lane % LPT) == 0 && t < batch) Elem<DT>::st(y, (int64_t)t * ldy + row, r);
+#pragma unroll
+    for (int tt = 0; tt < NTOK; ++tt) acc[tt] = 0.0f;
+  }
+}
+
+template <int T, int DT, int NTOK>
+static int launch_mmq_small_n(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
+                              int64_t ldy, hipStream_t s) {
+  const size_t lds = (size_t)NTOK * (k / 32) * 48 + (size_t)NTOK * (k / 32) * 4;
+  if (lds > 160 * 1024) return -100;  // caller falls back to the tiled kernel
+  auto kern = mmq_small_kernel<T, DT, NTOK>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GGQ_ERR_LAUNCH;
+  }
+  // one 16-wave workgroup per CU: the activation staging (tens of KB) is paid once per CU
+  int rpw = (int)((n + 256 * 16 - 1) / (256 * 16));
+  rpw = rpw < 1 ? 1 : rpw;
+  const int64_t waves = (n + rpw - 1) / rpw;
+  const int64_t grid = (waves + 15) / 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, (const uint8_t*)w, (const uint8_t*)q8, y,
+                     (int)k, (int)n, (int)batch, ldy, rpw);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
+}
+
+template <int T, int DT>
+static int launch_mmq_small(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
+                            int64_t ldy, hipStream_t s) {
+  if (batch <= 2) return launch_mmq_small_n<T, DT, 2>(w, q8, y, batch, k, n, ldy, s);
+  if (batch <= 4) return launch_mmq_small_n<T, DT, 4>(w, q8, y, batch, k, n, ldy, s);
+  if (batch <= 8) return launch_mmq_small_n<T, DT, 8>(w, q8, y, batch, k, n, ldy, s);
+  return launch_mmq_small_n<T, DT, 16>(w, q8, y, batch, k, n, ldy, s);
+}
+
 template <int T, int DT>
 static int launch_mmq_t(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                         int64_t ldy, hipStream_t s) {
+  if (batch <= 16) {  // HBM-bound regime: stream the weights once, dot4 against every token
+    static const char* e = getenv("GGQ_MMQ_SMALL");
+    if (!e || e[0] != '0') {
+      const int rc = launch_mmq_small<T, DT>(w, q8, y, batch, k, n, ldy, s);
+      if (rc != -100) return rc;
+    }
+  }
   if (batch <= 32) return launch_mmq_cfg<T, DT, 1>(w, q8, y, batch, k, n, ldy, s);
   // 64-token units give the dispatcher 2x more, smaller units to balance (688 vs 344 at the headline
   // shape); 128-token units halve the weight re-staging once there are plenty of units anyway
