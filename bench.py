@@ -265,11 +265,13 @@ def main():
 
     if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel (mul_mat_q alone, activations pre-quantised) ----
-        rc = L.ggq_quantize_q8_1_mmq(vp(x), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
+        # (the fused op quantises into the fragment-major scratch and runs the streamed kernel for Q4_K:
+        #  time exactly that kernel, through the exported pre-quantised entry point)
+        rc = L.ggq_quantize_q8_1_tiled(vp(x), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
         assert rc == 0
 
         def mmq_only():
-            L.ggq_mul_mat_q_prequant(vp(w), vp(scratch), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+            L.ggq_mul_mat_q_pretiled(vp(w), vp(scratch), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
 
         us_med, us_min = time_launches(mmq_only, 200, use_graph=not args.eager)
         achieved = bytes_per_step / (us_med * 1e-6) / 1e9
@@ -278,7 +280,7 @@ def main():
             traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["mmq_q4_k_batch128"]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "ggq::mmq_kernel<Q4_K, f16, TBn=2> (32 rows x 64 tokens per workgroup)",
+        out["roofline"] = {"bound": "hbm", "kernel": "ggq::mmq_stream_kernel<Q4_K, f16, TB=2> (32 rows x 64 tokens x 4 K-slices per workgroup)",
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "avg_launch_us": round(us_med, 3), "min_launch_us": round(us_min, 3),
@@ -337,6 +339,12 @@ def secondary_configs(L, dev, w_q4k, x128, scratch, args):
         rec(f"mmq_{names[t]}_batch8", us, algo_bytes_matmul(t, N_DIM, K_DIM, 8), 2.0 * 8 * N_DIM * K_DIM)
     us, _ = time_launches(lambda: L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 200, use_graph=g)
     res["quantize_mmq_q8_1_batch128"] = {"us": round(us, 3)}
+    us, _ = time_launches(lambda: L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 200, use_graph=g)
+    res["quantize_q8_1_tiled_batch128"] = {"us": round(us, 3)}
+    # the reference-layout kernel (other formats' path) on the headline shape, for comparison
+    L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
+    us, _ = time_launches(lambda: L.ggq_mul_mat_q_prequant(vp(w_q4k), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream()), 100, use_graph=g)
+    rec("mmq_Q4_K_batch128_lds_tile_kernel_only", us, algo_bytes_matmul(Q4_K, N_DIM, K_DIM, BATCH), 2.0 * BATCH * N_DIM * K_DIM)
     return res
 
 

@@ -50,7 +50,7 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
 def _common_deps():
@@ -58,9 +58,14 @@ def _common_deps():
 
 
 def build_hip(force=False, verbose=False):
+    so = os.path.join(LIB, "libggq_hip.so")
+    sources = [os.path.join(CSRC, "hip", n + ".hip") for n in HIP_SOURCES] + [TRAITS_SRC] + _common_deps()
+    if not force and not _stale(so, sources):
+        return so  # prebuilt library newer than every source (the object cache need not exist: GPU box)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB, exist_ok=True)
     hipcc = _hipcc()
+    extra = os.environ.get("GGQ_HIPCC_FLAGS", "").split()   # kernel experiments: -D switches
     objs, jobs = [], []
     for name in HIP_SOURCES:
         src = os.path.join(CSRC, "hip", name + ".hip")
@@ -68,7 +73,7 @@ def build_hip(force=False, verbose=False):
         objs.append(obj)
         if force or _stale(obj, [src] + _common_deps()):
             cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fno-gpu-rdc",
-                   "-Wno-unused-result", "-c", src, "-o", obj]
+                   "-Wno-unused-result", *extra, "-c", src, "-o", obj]
             if name in NO_CONTRACT:
                 cmd.insert(1, "-ffp-contract=off")
             jobs.append(cmd)
@@ -83,7 +88,6 @@ def build_hip(force=False, verbose=False):
     if force or _stale(tobj, [TRAITS_SRC, os.path.join(INCLUDE, "ggq.h")]):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-c", TRAITS_SRC, "-o", tobj])
         relink = True
-    so = os.path.join(LIB, "libggq_hip.so")
     if force or relink or _stale(so, objs):
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", so] + objs)
     return so

@@ -75,5 +75,6 @@ extern "C" size_t ggq_mmvq_scratch_bytes(int64_t k) {
   return (size_t)(ggq_mmvq_padded_k(k) / 32 * 36);
 }
 extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
-  return (size_t)batch * (size_t)(ggq_mmq_padded_k(k) / 32 * 36);
+  // whole 32-token tiles: the fragment-major layout (ggq_quantize_q8_1_tiled) addresses tiles
+  return (size_t)((batch + 31) / 32 * 32) * (size_t)(ggq_mmq_padded_k(k) / 32 * 36);
 }

@@ -23,6 +23,9 @@ __device__ __forceinline__ void load4(const void* x, int64_t base, int64_t ix, i
 
 // LAYOUT 0: block_q8_1 {half d; half s; int8 qs[32]}, row-major [batch][padded/32]
 // LAYOUT 1: block_q8_1_mmq {half2 ds[4]; int8 qs[128]}, index (ix/128)*batch + token
+// LAYOUT 2: the same 144 bytes per (128 elements, token), regrouped so that one MFMA B fragment
+//           (32 tokens x 32 elements) is 1 KB contiguous in lane order: per (ix/128, token/32) a
+//           4608-byte tile { int8 qs[4 groups][2 halves][32 tokens][16]; ds[2 pairs][32 tokens][2] }
 template <int DT, int LAYOUT, bool NEED_SUM>
 __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restrict__ x,
                                                             uint8_t* __restrict__ q, int64_t batch,
@@ -66,6 +69,21 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
       const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
       const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
       *(uint32_t*)blk = (uint32_t)hd | ((uint32_t)hs << 16);
+    }
+  } else if (LAYOUT == 2) {
+    const int64_t n_tt = (batch + 31) >> 5;
+    uint8_t* tile = q + ((g >> 2) * n_tt + (t >> 5)) * 4608;
+    const int slot = (int)(g & 3), tl = (int)(t & 31);
+    *(uint32_t*)(tile + slot * 1024 + (e >> 4) * 512 + tl * 16 + (e & 15)) = packed;
+    if (e == 0) {
+      uint8_t* ds = tile + 4096 + (slot >> 1) * 256 + tl * 8 + (slot & 1) * 4;
+      if (NEED_SUM) {
+        const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+        const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
+        *(uint32_t*)ds = (uint32_t)hd | ((uint32_t)hs << 16);
+      } else {
+        *(float*)ds = d;
+      }
     }
   } else {
     uint8_t* blk = q + ((g >> 2) * batch + t) * 144;
@@ -122,6 +140,21 @@ extern "C" int ggq_quantize_q8_1(const void* x, int x_dtype, void* q, int64_t ba
   if (!x || !q) return GGQ_ERR_ARG;
   if ((uintptr_t)q & 3) return GGQ_ERR_ALIGN;
   return launch_quant<0, true>(x, x_dtype, q, batch, k, ggq_mmvq_padded_k(k), (hipStream_t)stream);
+}
+
+extern "C" int ggq_quantize_q8_1_tiled(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                                       int type, void* stream) {
+  using namespace ggq;
+  if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
+  if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (batch == 0) return GGQ_OK;
+  if (!x || !q) return GGQ_ERR_ARG;
+  if ((uintptr_t)q & 15) return GGQ_ERR_ALIGN;
+  const int64_t padded = ggq_mmq_padded_k(k);
+  if (ggq_mmq_need_sum(type))
+    return launch_quant<2, true>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream);
+  return launch_quant<2, false>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream);
 }
 
 extern "C" int ggq_quantize_q8_1_mmq(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,

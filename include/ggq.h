@@ -79,7 +79,8 @@ int ggq_mmq_need_sum(int type);
  *   MMQ : k - k%512 + 512         (HK/ggml/mmq.cu:190-191) */
 int64_t ggq_mmvq_padded_k(int64_t k);
 int64_t ggq_mmq_padded_k(int64_t k);
-/* scratch bytes = batch * padded/32 * 36 (HK/ggml/ggml_kernel.cu:90, mmq.cu:208) */
+/* scratch bytes = batch * padded/32 * 36 (HK/ggml/ggml_kernel.cu:90, mmq.cu:208); the MMQ
+ * figure rounds batch up to a multiple of 32 (whole token tiles of the fragment-major layout) */
 size_t ggq_mmvq_scratch_bytes(int64_t k);
 size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k);
 
@@ -127,6 +128,20 @@ int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type, int dtype,
 /* mul_mat_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1_mmq).
  * Lets a caller quantise X once and reuse it for several weight matrices. */
 int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int type, int dtype,
+                           int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                           void* stream);
+
+/* Fragment-major variant of the MMQ activation scratch (same 144 bytes per 128 elements and token,
+ * same values as ggq_quantize_q8_1_mmq, regrouped per (k/128, token/32) into 4608-byte tiles
+ * { int8 qs[4 groups][2 K-halves][32 tokens][16]; ds[2 group pairs][32 tokens][2] } so that one MFMA
+ * operand fragment is 1 KB contiguous).  This is what ggq_mul_mat_q uses internally for the formats
+ * ggq_mmq_tiled_supported() reports (Q4_K / Q5_K with k % 256 == 0); exported so a caller can quantise
+ * once for several weight matrices (as the reference does per layer, HK/ggml/mmq.cu:208-230).
+ * q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte aligned.  w must be 16-byte aligned. */
+int ggq_mmq_tiled_supported(int type, int64_t k);
+int ggq_quantize_q8_1_tiled(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                            int type, void* stream);
+int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int type, int dtype,
                            int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                            void* stream);
 

@@ -4,11 +4,14 @@
   integer / byte work (dequantise bit patterns, Q8_1 bytes)  -> bit-exact
   fp accumulate (MMVQ / MMQ)                                  -> 1e-3 relative (north_star)
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
 
 from ggq import synth
+from ggq import lib as ggqlib
 from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM, row_bytes
 import util
 
@@ -90,7 +93,21 @@ def test_quantize_q8_1_mmq_bit_exact(oracle, dtype, t, batch, k):
     x = _x((batch, k), dtype, seed=batch + k)
     got = util.gpu_quantize_q8_1_mmq(x, t)
     ref = oracle.quantize_q8_1_mmq(x.float().cpu().numpy(), t)
-    assert np.array_equal(got, ref), "block_q8_1_mmq bytes differ from the oracle"
+    # (the scratch is sized for whole 32-token tiles; the reference layout uses its first batch*... bytes)
+    assert np.array_equal(got[:ref.size], ref.reshape(-1)), "block_q8_1_mmq bytes differ from the oracle"
+    assert not got[ref.size:].any(), "bytes beyond the reference layout were written"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0], ids=lambda t: t.name)  # need_sum / not
+@pytest.mark.parametrize("batch,k", [(1, 256), (31, 512), (32, 256), (33, 1024), (130, 4096), (70, 768)])
+def test_quantize_q8_1_tiled_bit_exact(oracle, dtype, t, batch, k):
+    """fragment-major scratch = the oracle's block_q8_1_mmq bytes, regrouped (tokens past the batch in the
+    last 32-token tile are never written: the test buffer is zero-initialised, so they compare as zeros)"""
+    x = _x((batch, k), dtype, seed=batch + k)
+    got = util.gpu_quantize_q8_1_tiled(x, t)
+    ref, n_tt = util.retile_q8_1_mmq(oracle.quantize_q8_1_mmq(x.float().cpu().numpy(), t), batch, k)
+    assert np.array_equal(got[:ref.size].reshape(ref.shape), ref), "fragment-major bytes differ from the re-tiled oracle"
 
 
 # ---------------------------------------------------------------- MMVQ
@@ -136,6 +153,66 @@ def test_mmq_k_not_multiple_of_256(oracle, t):
     y = util.gpu_mmq(w, x, t, n_rows)
     ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
     util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"mmq {t.name}")
+
+
+STREAM_TYPES = [GGMLType.Q4_K, GGMLType.Q5_K]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=str)
+@pytest.mark.parametrize("t", STREAM_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("batch,k,n_rows", [(5, 256, 33), (17, 768, 31), (32, 1024, 64), (33, 256, 1), (64, 2304, 70),
+                                            (65, 1280, 95), (128, 4096, 160), (129, 512, 32), (300, 256, 257)])
+def test_mmq_streamed_vs_oracle(oracle, dtype, t, batch, k, n_rows):
+    """The streamed kernel (32- and 64-token units, ragged row / token tiles, 1..18 K stages per wave,
+    K-slices of unequal length, fewer stages than K-slices) against the oracle."""
+    assert ggqlib.hip().ggq_mmq_tiled_supported(int(t), k) == 1
+    w = synth.random_weight(t, n_rows, k, seed=batch + k)
+    x = _x((batch, k), dtype, seed=14)
+    y = util.gpu_mmq_pretiled(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, dtype, f"streamed mmq {t.name} b={batch}")
+
+
+def test_mmq_streamed_ldy_and_errors(oracle):
+    """row pitch (the multi-GPU slab write) + the argument checks of the fragment-major entry points"""
+    L = ggqlib.hip()
+    t, batch, k, n_rows, ldy = GGMLType.Q4_K, 70, 512, 40, 104
+    w = synth.random_weight(t, n_rows, k, seed=5)
+    x = _x((batch, k), torch.float16, seed=15)
+    y = util.gpu_mmq_pretiled(w, x, t, n_rows, ldy=ldy)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y[:, :n_rows], ref, yabs, torch.float16, "streamed mmq ldy")
+    assert torch.count_nonzero(y[:, n_rows:]) == 0, "columns beyond n_rows were written"
+    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q4_0), 4096) == 0
+    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q8_0), 4096) == 0
+    q = torch.zeros(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    wd = util.dev_bytes(w)
+    st = util.stream_ptr()
+    assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(GGMLType.Q8_0), 1, batch, k, n_rows, ldy, st) == -1
+    assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(t), 7, batch, k, n_rows, ldy, st) == -3
+    assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(t), 1, batch, k, n_rows, n_rows - 1, st) == -4
+    assert L.ggq_mul_mat_q_pretiled(ctypes.c_void_p(wd.data_ptr() + 2), util.vp(q), util.vp(y), int(t), 1, batch, k, n_rows, ldy, st) == -6
+    assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(t), 1, 0, k, n_rows, ldy, st) == 0
+    assert L.ggq_quantize_q8_1_tiled(util.vp(x), 1, ctypes.c_void_p(q.data_ptr() + 4), batch, k, int(t), st) == -6
+
+
+def test_mmq_weight_pointer_not_16_aligned(oracle):
+    """GGUF tensors are 32-byte aligned, but the ABI only asks for 2: the fused op must fall back to the
+    reference-layout kernel for an odd weight pointer and still agree with the oracle."""
+    L = ggqlib.hip()
+    t, batch, k, n_rows = GGMLType.Q4_K, 40, 512, 48
+    w = synth.random_weight(t, n_rows, k, seed=6)
+    x = _x((batch, k), torch.float32, seed=16)
+    buf = torch.zeros(w.size + 64, dtype=torch.uint8, device="cuda")
+    off = (-buf.data_ptr()) % 16 + 2
+    buf[off:off + w.size] = torch.from_numpy(w.reshape(-1)).cuda()
+    y = torch.empty((batch, n_rows), dtype=torch.float32, device="cuda")
+    scratch = torch.empty(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_mul_mat_q(ctypes.c_void_p(buf.data_ptr() + off), util.vp(x), util.vp(y), int(t), 0, batch, k,
+                                 n_rows, util.vp(scratch), util.stream_ptr()), "ggq_mul_mat_q")
+    torch.cuda.synchronize()
+    ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, torch.float32, "mmq unaligned w")
 
 
 def test_mmq_integer_exact(oracle):

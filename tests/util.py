@@ -50,6 +50,53 @@ def gpu_quantize_q8_1_mmq(x, t):
     return q.cpu().numpy()
 
 
+def gpu_quantize_q8_1_tiled(x, t):
+    L = ggqlib.hip()
+    batch, k = x.shape
+    q = torch.zeros(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_quantize_q8_1_tiled(vp(x), ggqlib.dtype_code(x.dtype), vp(q), batch, k, int(t), stream_ptr()),
+                 "quantize_tiled")
+    torch.cuda.synchronize()
+    return q.cpu().numpy()
+
+
+def retile_q8_1_mmq(q_mmq, batch, k):
+    """block_q8_1_mmq bytes (index (k/128)*batch + token) -> the fragment-major layout of
+    ggq_quantize_q8_1_tiled, built independently in numpy: per (k/128, token/32) a 4608-byte tile
+    { qs[4 groups][2 halves][32 tokens][16]; ds[2 pairs][32 tokens][2 groups][4 bytes] }."""
+    padded = k - k % 512 + 512
+    n_kb, n_tt = padded // 128, (batch + 31) // 32
+    blocks = np.asarray(q_mmq, np.uint8)[:n_kb * batch * 144].reshape(n_kb, batch, 144)
+    out = np.zeros((n_kb, n_tt, 4608), np.uint8)
+    for t in range(batch):
+        tt, tl = divmod(t, 32)
+        ds = blocks[:, t, :16].reshape(n_kb, 4, 4)          # [kb][group][4 bytes]
+        qs = blocks[:, t, 16:].reshape(n_kb, 4, 2, 16)      # [kb][group][half][16]
+        for g in range(4):
+            for h in range(2):
+                o = g * 1024 + h * 512 + tl * 16
+                out[:, tt, o:o + 16] = qs[:, g, h]
+            o = 4096 + (g >> 1) * 256 + tl * 8 + (g & 1) * 4
+            out[:, tt, o:o + 4] = ds[:, g]
+    return out, n_tt
+
+
+def gpu_mmq_pretiled(w_np, x, t, n_rows, ldy=None):
+    """quantise once into the fragment-major scratch, then the streamed kernel alone"""
+    L = ggqlib.hip()
+    batch, k = x.shape
+    ldy = n_rows if ldy is None else ldy
+    w = dev_bytes(w_np)
+    y = torch.zeros((batch, ldy), dtype=x.dtype, device="cuda")
+    q = torch.empty(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    dt = ggqlib.dtype_code(x.dtype)
+    ggqlib.check(L.ggq_quantize_q8_1_tiled(vp(x), dt, vp(q), batch, k, int(t), stream_ptr()), "quantize_tiled")
+    ggqlib.check(L.ggq_mul_mat_q_pretiled(vp(w), vp(q), vp(y), int(t), dt, batch, k, n_rows, ldy, stream_ptr()),
+                 "ggq_mul_mat_q_pretiled")
+    torch.cuda.synchronize()
+    return y
+
+
 def gpu_mmvq(w_np, x, t, n_rows):
     L = ggqlib.hip()
     k = x.shape[1]
