@@ -1026,36 +1026,62 @@ extern "C" int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int
 
 namespace ggq {
 // ---------------------------------------------------------------------------------------------
-// Streamed kernel (Q4_K / Q5_K, tiled activations): the register-direct kernel with the two memory
-// paths fixed.  Measured on the register-direct kernel: per-lane row loads touch one 128-byte L1
-// line per 16 useful bytes, so the weight loads alone cost as much L1 time as all activations.
-//   * weights: each wave copies the raw bytes of its 32 rows x 256 elements (one super-block per row)
-//     with LDS-DMA, consecutive lanes = consecutive 16-byte chunks of a row (coalesced), into a
-//     wave-private two-stage ring, a full stage (four pair-iterations) ahead — the HBM latency of
-//     the weight stream is off the critical path.  Lanes then read their own row's 16 nibble bytes and
-//     the 16-byte header from LDS (144/176-byte row pitch: conflict-free ds_read_b128).
+// Streamed kernel (all formats, fragment-major activations).  No workgroup barrier in the K loop:
+//   workgroup = 4 waves = 4 K-slices of one unit (32 weight rows x 32·TB tokens); every wave is an
+//   independent instruction stream, so a SIMD interleaves its waves freely (the barrier-coupled kernel
+//   above spends more time at barriers than computing).  The K loop is VALU-issue bound: per
+//   (row, token, 32-group) triple two FMAs (three with an fp32 d8) — DESIGN.md §5.4.
+//   * weights: a wave copies the raw bytes of its 32 rows x one K stage (256 elements, 128 for the wide
+//     legacy blocks) as 16-byte chunks, consecutive lanes = consecutive chunks of a row (per-lane row loads
+//     would touch one 128-byte L1 line per 16 useful bytes: measured, they cost as much L1 time as all
+//     activations), into a wave-private two-stage LDS ring, one stage ahead: the HBM latency of the
+//     weight stream is off the critical path.  (Plain loads + ds_write, not LDS-DMA: with DMA operations
+//     in flight the compiler's waitcnt pass degrades every later vector-memory wait to vmcnt(0).)
+//   * A fragments.  Q4_K/Q5_K: lane (r, h) reads bytes 16h..16h+15 of the pair's 32 nibble bytes from its
+//     row in the ring: low nibbles are its fragment of group 2p, high nibbles of group 2p+1.  Other
+//     formats: the lane unpacks the whole group 2p+h (the same unpack_raw as the kernels above: MMQ canon)
+//     and one v_permlane32_swap per dword hands the two lane halves their K-halves of both groups.
+//   * the per-(row, group) scale must be seen per accumulator register: 64 floats per pair go through a
+//     wave-private LDS line (one ds_write_b32, broadcast ds_read_b128) — same wave, no barrier.
 //   * activations: fragment-major tiles (LAYOUT 2 of quantize.hip): one B fragment = 1 KB contiguous in
-//     lane order; the registers of a fragment are reloaded for the next pair right after the MFMA that
-//     consumed them was issued (a full iteration of lead, no second register set).
-//   * no workgroup barrier in the K loop; s_waitcnt vmcnt only at stage boundaries.
+//     lane order; a fragment's registers are reloaded for the next pair right after the MFMA that consumed
+//     them was issued (a full iteration of lead, no second register set).
+//   * K-slice partial sums meet once per unit in LDS.  blockIdx -> unit is XCD-aware: the units of one XCD
+//     are consecutive, so a weight row tile is fetched into one L2 only.
 // ---------------------------------------------------------------------------------------------
-template <int T> struct StreamLds {
-  static constexpr int STAGE = ((28 * Fmt<T>::BS + 1024 + 127) / 128) * 128;  // rows 0-31 + overrun of window 7
-  static constexpr int WAVE = 2 * STAGE + 512;                               // + scale exchange line
+template <int T> struct StreamCfg {
+  using TR = MmqTraits<T>;
+  static constexpr bool direct = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;
+  static constexpr int QK = Fmt<T>::QK, BS = Fmt<T>::BS;
+  static constexpr int SE = (QK == 256 || 8 * BS <= 176) ? 256 : 128;   // elements of K per ring stage
+  static constexpr int SEG = SE / QK * BS;               // bytes of one row in one stage
+  static constexpr int IPS = SE / 64;                    // pair-iterations per stage
+  static constexpr int CPR = (SEG + 15) / 16;            // 16-byte chunks per row (the last may overlap)
+  // LDS row pitch.  A misaligned ds_read/write_b128 costs 3.4x an aligned one (measured: 56 vs 16 cycles), so
+  // super-block formats (one block per row per stage, fields at 16-byte multiples) get a 16-byte-multiple
+  // pitch; the 2-4 tail bytes of a 210/110/84-byte block are parked with a narrow store.  The legacy
+  // formats keep their 18/20/22/24/34-byte blocks back to back (their quant bytes are misaligned anyway).
+  static constexpr int TAIL = QK == 256 ? SEG % 16 : 0;  // bytes of the last, partial chunk (0: none)
+  static constexpr int PITCH = TAIL ? 16 * CPR : SEG;
+  static constexpr int RPW = 64 / CPR;     // rows per copy window (one 64-lane load)
+  static constexpr int NW = (32 + RPW - 1) / RPW;        // windows per stage
+  static constexpr int WPI = (NW + IPS - 1) / IPS;       // windows per iteration
+  static constexpr int STAGE = ((NW * RPW * PITCH + 16 + 127) / 128) * 128;
+  static constexpr int SBUF = 512;                       // [s0 | s1][group of the pair][row] floats
+  static constexpr int WAVE = 2 * STAGE + SBUF;
+  // three workgroups per CU (168 VGPRs, <= 53 KB LDS) except Q6_K: two result tiles per group and a 210-byte row
+  static constexpr int OCC = TR::half_scales ? 2 : 3;
 };
 
 template <int T, int DT, int TB>
-__global__ void __launch_bounds__(256, 3) mmq_stream_kernel(const uint8_t* __restrict__ w,
+__global__ void __launch_bounds__(256, StreamCfg<T>::OCC) mmq_stream_kernel(const uint8_t* __restrict__ w,
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
                                                             int64_t ldy, int n_tok_tiles, int n_units, int per_xcd) {
-  static_assert(T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K, "super-block formats with 16-byte multiples only");
-  constexpr int SEG = Fmt<T>::BS;              // bytes of one row in one 256-element stage
-  constexpr int CPR = SEG / 16;                // 16-byte chunks per row
-  constexpr int STAGE = StreamLds<T>::STAGE;   // 8 LDS-DMA windows of 1 KB, window m starts at row 4m
-  constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : off::Q5_K_QS;
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave]{ ring[2][STAGE]; float sb[2][32] }
-  constexpr int WAVE_LDS = StreamLds<T>::WAVE;
+  using C = StreamCfg<T>;
+  using TR = MmqTraits<T>;
+  constexpr int SEG = C::SEG, STAGE = C::STAGE, IPS = C::IPS;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave]{ ring[2][STAGE]; float sb[2][2][32] }
 
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (unit >= n_units) return;
@@ -1064,37 +1090,71 @@ __global__ void __launch_bounds__(256, 3) mmq_stream_kernel(const uint8_t* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const uint32_t row_bytes = (uint32_t)(k / 256) * SEG;
-  const int n_st = k / 256;
+  const uint32_t row_bytes = (uint32_t)(k / C::QK) * C::BS;
+  const int n_groups = k / 32;
+  const int n_st = (k + C::SE - 1) / C::SE;
   const int st_begin = (int)((int64_t)ks * n_st / 4), st_end = (int)((int64_t)(ks + 1) * n_st / 4);
-  uint8_t* ring = lds + ks * WAVE_LDS;
+  uint8_t* ring = lds + ks * C::WAVE;
   float* sb = (float*)(ring + 2 * STAGE);
   const int n_tt32 = (batch + 31) / 32;
   const uint32_t lane16 = lane * 16;
   const uint8_t* wtile = w + (int64_t)n0 * row_bytes;
   GGQ_STAMP(0);
 
-  // ---- weight stage copy: window m (1 KB, lane-linear in LDS) starts at row 4m; lane = chunk lane%CPR of
-  //      row 4m + lane/CPR.  Neighbouring windows overlap with identical bytes; two windows per iteration. ----
-  const int lrow = lane / CPR, lchunk = lane % CPR;
+  // ---- weight stage copy: window m = rows [m·RPW, (m+1)·RPW) of the stage, lane = chunk lane % CPR of row
+  //      lane / CPR (lanes past RPW·CPR and rows past 31 repeat valid bytes into unused ring space).  The last
+  //      chunk of a row ends exactly at the row's stage bytes (it may overlap its neighbour), so no load
+  //      ever leaves the weight tensor. ----
+  const int lrow = min(lane / C::CPR, C::RPW - 1), lchunk = lane % C::CPR;
   const int rmax = min(31, n_rows - 1 - n0);
-  // (plain loads + ds_write rather than LDS-DMA: with DMA operations in flight the compiler's waitcnt pass
-  //  degrades every later vector-memory wait to vmcnt(0), which serialises the activation prefetch)
-  auto load_window = [&](int st_src, int m) {
-    const uint32_t off = (uint32_t)min(4 * m + lrow, rmax) * row_bytes + 16 * lchunk;
-    return *(const v4i*)(wtile + (int64_t)st_src * SEG + off);
+  // byte offset of this lane's chunk inside the row's stage bytes; super-block formats have no K tail
+  const uint32_t lcoff = (uint32_t)min(16 * lchunk, (int)SEG - 16);
+  auto chunk_off = [&](int st_src) {
+    if constexpr (C::QK == 256) return lcoff;
+    else return (uint32_t)min(16 * lchunk, min((int)SEG, (int)(row_bytes - (uint32_t)st_src * SEG)) - 16);
   };
-  auto store_window = [&](const v4i& v, int buf, int m) { *(v4i*)(ring + buf * STAGE + 4 * m * SEG + lane16) = v; };
+  // per-lane constants + scalar (window, stage) terms: no vector multiply in the loop
+  const uint32_t lrow_off = (uint32_t)lrow * row_bytes, rmax_off = (uint32_t)rmax * row_bytes;
+  const uint32_t lds_lane = (uint32_t)lrow * C::PITCH;
+  auto load_window = [&](int st_src, int m) {
+    const uint32_t sbase = (uint32_t)(m * C::RPW) * row_bytes + (uint32_t)st_src * SEG;   // scalar
+    const uint32_t srmax = rmax_off + (uint32_t)st_src * SEG;                             // scalar
+    // row m·RPW + lrow, clamped to the tile's last valid row
+    const uint32_t roff = lrow <= rmax - m * C::RPW ? sbase + lrow_off : srmax;
+    return ld_u32x4(wtile + (roff + chunk_off(st_src)));
+  };
+  auto store_window = [&](const u32x4_a2& v, int st_src, int buf, int m) {
+    uint8_t* dst = ring + (uint32_t)(buf * STAGE + m * C::RPW * C::PITCH) + lds_lane;
+    if constexpr (C::TAIL != 0) {
+      // aligned 16-byte chunks; the last chunk was loaded ending at the block end: its final TAIL bytes
+      // (fp16 d / half2 dm / Q3_K scales + d) go to offset 16 (CPR - 1) with narrow stores
+      static_assert(C::TAIL == 2 || C::TAIL == 4 || C::TAIL == 14, "tail store widths");
+      if (lchunk < C::CPR - 1) *(v4i*)(dst + 16 * lchunk) = v4i{(int)v.v[0], (int)v.v[1], (int)v.v[2], (int)v.v[3]};
+      else if constexpr (C::TAIL == 2) *(uint16_t*)(dst + 16 * (C::CPR - 1)) = (uint16_t)(v.v[3] >> 16);
+      else if constexpr (C::TAIL == 4) *(uint32_t*)(dst + 16 * (C::CPR - 1)) = v.v[3];
+      else {   // Q3_K: 14 bytes = scales (12) + d (2): bytes 2..15 of the chunk loaded at SEG - 16
+        *(uint16_t*)(dst + 16 * (C::CPR - 1)) = (uint16_t)(v.v[0] >> 16);
+        *(uint32_t*)(dst + 16 * (C::CPR - 1) + 2) = v.v[1];   // 2-byte aligned dword stores: rare lanes only
+        *(uint32_t*)(dst + 16 * (C::CPR - 1) + 6) = v.v[2];
+        *(uint32_t*)(dst + 16 * (C::CPR - 1) + 10) = v.v[3];
+      }
+    } else {
+      *(u32x4_a2*)(dst + chunk_off(st_src)) = v;
+    }
+  };
 
-  // ---- activations (LAYOUT 2 tiles of 4608 bytes): per token block a scalar pointer to the pair's 2 KB of
-  //      fragments; the half2(d, sum) pairs sit 4096 (even pair) / 2304 (odd pair) bytes further ----
-  const int64_t kb_stride = (int64_t)n_tt32 * 4608;
+  // ---- activations (LAYOUT 2 tiles of 4608 bytes per 128 elements x 32 tokens): abase[] points at the
+  //      current pair's 2 KB of fragments; its half2(d, sum) / float d pairs sit 4096 (even pair) or
+  //      2304 (odd pair) bytes further ----
   typedef const __attribute__((address_space(1))) uint8_t* gptr;   // keeps the loads global_load (not flat)
+  typedef const __attribute__((address_space(1))) v4i* gptr_v4i;
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) v2u* gptr_v2u;
+  const int64_t kb_stride = (int64_t)n_tt32 * 4608;
   gptr abase[TB];
 #pragma unroll
   for (int jj = 0; jj < TB; ++jj) abase[jj] = (gptr)q8 + (int64_t)min((t0 >> 5) + jj, n_tt32 - 1) * 4608;
   const uint32_t r8 = r * 8;
-  // fragment pointer of pair p: abase + (p >> 1) * kb_stride + (p & 1) * 2048, advanced incrementally
 
   v16f acc[TB];
 #pragma unroll
@@ -1106,23 +1166,22 @@ __global__ void __launch_bounds__(256, 3) mmq_stream_kernel(const uint8_t* __res
   for (int i = 0; i < 16; ++i) magic[i] = (int)MAGIC_I;
 
   v4i B[TB][2];
-  uint32_t ds0[TB], ds1[TB];   // half2(d, sum) of groups 2p / 2p+1 (separate scalars: never indexed by a lane value)
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  uint32_t ds0[TB], ds1[TB];   // d8 (+ sum) words of groups 2p / 2p+1 (separate scalars: never indexed by a lane value)
   v2u dsn[TB];
-  v4i wq[2];                   // two windows of the next stage in flight
-  const int p_begin = 4 * st_begin, p_end = 4 * st_end;
+  u32x4_a2 wq[C::WPI];         // windows of the next stage in flight
+  const int p_begin = IPS * st_begin, p_end = IPS * st_end;
   if (p_begin < p_end) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) store_window(load_window(st_begin, m), st_begin & 1, m);
+    for (int m = 0; m < C::NW; ++m) store_window(load_window(st_begin, m), st_begin, st_begin & 1, m);
     const int st1 = min(st_begin + 1, st_end - 1);
-    wq[0] = load_window(st1, 0);
-    wq[1] = load_window(st1, 1);
+#pragma unroll
+    for (int i = 0; i < C::WPI; ++i) wq[i] = load_window(st1, min(i, C::NW - 1));
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj) {
-      abase[jj] += (int64_t)(p_begin >> 1) * kb_stride;   // p_begin is even
-      B[jj][0] = *(const __attribute__((address_space(1))) v4i*)(abase[jj] + lane16);
-      B[jj][1] = *(const __attribute__((address_space(1))) v4i*)(abase[jj] + 1024 + lane16);
-      dsn[jj] = *(const __attribute__((address_space(1))) v2u*)(abase[jj] + 4096 + r8);
+      abase[jj] += (int64_t)(p_begin >> 1) * kb_stride + (p_begin & 1) * 2048;
+      B[jj][0] = *(gptr_v4i)(abase[jj] + lane16);
+      B[jj][1] = *(gptr_v4i)(abase[jj] + 1024 + lane16);
+      dsn[jj] = *(gptr_v2u)(abase[jj] + ((p_begin & 1) ? 2304 : 4096) + r8);
     }
   }
 #if GGQ_ABL & 32
@@ -1131,85 +1190,156 @@ __global__ void __launch_bounds__(256, 3) mmq_stream_kernel(const uint8_t* __res
 #endif
 
   for (int p = p_begin; p < p_end; ++p) {
-    const int st = p >> 2, q = p & 3;
+    const int st = p / IPS, q = p % IPS;
     // abase[] points at pair p; step to the next pair (the last iteration re-reads its own pair)
     const bool more = p + 1 < p_end;
-    const int64_t step = !more ? 0 : (q & 1) ? kb_stride - 2048 : 2048;
-    const int ds_off = (((q & 1) != 0) == more) ? 4096 : 2304;   // next pair even -> +4096, odd -> +2304
-    const uint8_t* stage = ring + (st & 1) * STAGE + r * SEG;
-    const v4i qs16 = *(const v4i*)(stage + QS + 32 * q + 16 * h);
-    const v4i hdr = *(const v4i*)stage;
+    const int64_t step = !more ? 0 : (p & 1) ? kb_stride - 2048 : 2048;
+    const int ds_off = (((p & 1) != 0) == more) ? 4096 : 2304;   // next pair even -> +4096, odd -> +2304
+    const uint8_t* stage = ring + (st & 1) * STAGE + r * C::PITCH;
+
+    // ---- raw weight bytes of this lane from the ring (before the ring is written below) ----
+    Raw R;
+    v4i qs16 = {}, hdr = {}, qh16 = {};
+    if constexpr (C::direct) {
+      constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : off::Q5_K_QS;
+      qs16 = *(const v4i*)(stage + QS + 32 * q + 16 * h);
+      hdr = *(const v4i*)stage;
+      if constexpr (T == GGQ_TYPE_Q5_K) qh16 = *(const v4i*)(stage + off::Q5_K_QH + 16 * h);
+    } else {
+      load_raw<T>(stage, 2 * q + h, R);
+    }
     __builtin_amdgcn_wave_barrier();
-    // park windows 2q, 2q+1 of the next stage (loaded during the previous iteration) in the other ring
-    // buffer, then start the loads of the following two windows (q = 3: windows 0, 1 of the stage after)
-    store_window(wq[0], (st + 1) & 1, 2 * q);
-    store_window(wq[1], (st + 1) & 1, 2 * q + 1);
+    // park the windows requested during the previous iteration (slot q of the stage after this one) in the
+    // other ring buffer, then request the windows iteration p + 1 will park.  Past the wave's last stage the
+    // source stage is clamped: valid bytes land in the dead buffer.
     {
-      const int stn = min((p + 5) >> 2, st_end - 1), qn = (p + 1) & 3;
-      wq[0] = load_window(stn, 2 * qn);
-      wq[1] = load_window(stn, 2 * qn + 1);
+      const int sw = min(st + 1, st_end - 1);
+#pragma unroll
+      for (int i = 0; i < C::WPI; ++i) store_window(wq[i], sw, (st + 1) & 1, min(q * C::WPI + i, C::NW - 1));
+      const int sn = min((p + 1) / IPS + 1, st_end - 1), qn = (p + 1) % IPS;
+#pragma unroll
+      for (int i = 0; i < C::WPI; ++i) wq[i] = load_window(sn, min(qn * C::WPI + i, C::NW - 1));
     }
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj) { ds0[jj] = dsn[jj][0]; ds1[jj] = dsn[jj][1]; }
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj) {
       abase[jj] += step;
-      dsn[jj] = *(const __attribute__((address_space(1))) v2u*)(abase[jj] + ds_off + r8);
+      dsn[jj] = *(gptr_v2u)(abase[jj] + ds_off + r8);
     }
 
-    // ---- A fragments of groups 2p, 2p+1 ----
-    v4i a[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a[0][i] = (int)((uint32_t)qs16[i] & 0x0F0F0F0Fu);
-      a[1][i] = (int)(((uint32_t)qs16[i] >> 4) & 0x0F0F0F0Fu);
-    }
-    if constexpr (T == GGQ_TYPE_Q5_K) {
-      const v4i qh16 = *(const v4i*)(stage + off::Q5_K_QH + 16 * h);
+    // ---- A fragments of groups 2p, 2p+1 and their scales ----
+    v4i a[2], a2[2];
+    float s0, s1;
+    if constexpr (C::direct) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        a[0][i] |= (int)((((uint32_t)qh16[i] >> (2 * q)) & 0x01010101u) << 4);
-        a[1][i] |= (int)((((uint32_t)qh16[i] >> (2 * q + 1)) & 0x01010101u) << 4);
+        a[0][i] = (int)((uint32_t)qs16[i] & 0x0F0F0F0Fu);
+        a[1][i] = (int)(((uint32_t)qs16[i] >> 4) & 0x0F0F0F0Fu);
+      }
+      if constexpr (T == GGQ_TYPE_Q5_K) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[0][i] |= (int)((((uint32_t)qh16[i] >> (2 * q)) & 0x01010101u) << 4);
+          a[1][i] |= (int)((((uint32_t)qh16[i] >> (2 * q + 1)) & 0x01010101u) << 4);
+        }
+      }
+      int sc, mn;   // scale / min of group 2q + h (get_scale_min_k4): q < 2 <=> group < 4
+      if (q < 2) {
+        sc = ((uint32_t)hdr[1] >> (16 * q + 8 * h)) & 63;
+        mn = ((uint32_t)hdr[2] >> (16 * q + 8 * h)) & 63;
+      } else {
+        const int sh = 16 * (q - 2) + 8 * h;
+        const uint32_t bb = ((uint32_t)hdr[3] >> sh) & 0xFF;
+        sc = (bb & 0xF) | ((((uint32_t)hdr[1] >> (sh + 6)) & 3) << 4);
+        mn = (bb >> 4) | ((((uint32_t)hdr[2] >> (sh + 6)) & 3) << 4);
+      }
+      s0 = bits_h_f32((uint32_t)hdr[0] & 0xFFFF) * (float)sc;
+      s1 = -(bits_h_f32((uint32_t)hdr[0] >> 16) * (float)mn);
+    } else {
+      uint32_t wv[8], wv2[8];
+      unpack_raw<T>(R, 2 * q + h, wv, wv2, s0, s1);
+      if (2 * p + h >= n_groups) {   // K tail of a legacy format: contributes nothing
+        s0 = 0.0f; s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wv[i] = 0; wv2[i] = 0; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // lanes 32-63 of wv[i] <-> lanes 0-31 of wv[4+i]: afterwards [0] = fragment of group 2p, [1] = of 2p+1
+        const auto sw = __builtin_amdgcn_permlane32_swap(wv[i], wv[4 + i], false, false);
+        a[0][i] = (int)sw[0]; a[1][i] = (int)sw[1];
+        if constexpr (TR::two_tiles) {
+          const auto sw2 = __builtin_amdgcn_permlane32_swap(wv2[i], wv2[4 + i], false, false);
+          a2[0][i] = (int)sw2[0]; a2[1][i] = (int)sw2[1];
+        }
       }
     }
-    int sc, mn;   // scale / min of group 2q + h (get_scale_min_k4): q < 2 <=> group < 4
-    if (q < 2) {
-      sc = ((uint32_t)hdr[1] >> (16 * q + 8 * h)) & 63;
-      mn = ((uint32_t)hdr[2] >> (16 * q + 8 * h)) & 63;
-    } else {
-      const int sh = 16 * (q - 2) + 8 * h;
-      const uint32_t bb = ((uint32_t)hdr[3] >> sh) & 0xFF;
-      sc = (bb & 0xF) | ((((uint32_t)hdr[1] >> (sh + 6)) & 3) << 4);
-      mn = (bb >> 4) | ((((uint32_t)hdr[2] >> (sh + 6)) & 3) << 4);
-    }
-    const float s0 = bits_h_f32((uint32_t)hdr[0] & 0xFFFF) * (float)sc;
-    const float s1 = -(bits_h_f32((uint32_t)hdr[0] >> 16) * (float)mn);
     sb[h * 32 + r] = s0;
+    if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb[64 + h * 32 + r] = s1;
     __builtin_amdgcn_wave_barrier();
 
-    // min term: Σ (-dmin·m)[row, 2p+h] · s8[token, 2p+h] on the matrix pipe
+    if constexpr (TR::mfma_min) {
+      // min term: Σ (-dmin·m)[row, 2p+h] · s8[token, 2p+h] on the matrix pipe
 #pragma unroll
-    for (int jj = 0; jj < TB; ++jj)
-      acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, bits_h_f32((h ? ds1[jj] : ds0[jj]) >> 16), acc[jj], 0, 0, 0);
+      for (int jj = 0; jj < TB; ++jj)
+        acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, bits_h_f32((h ? ds1[jj] : ds0[jj]) >> 16), acc[jj], 0, 0, 0);
+    }
 
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
-      v4f sa[4];
+      v4f sa[4], sbv[4];
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) sa[qd] = *(const v4f*)(sb + gg * 32 + 8 * qd + 4 * h);
+      for (int qd = 0; qd < 4; ++qd) {
+        sa[qd] = *(const v4f*)(sb + gg * 32 + 8 * qd + 4 * h);
+        if constexpr (TR::n_scale == 2 && !TR::mfma_min) sbv[qd] = *(const v4f*)(sb + 64 + gg * 32 + 8 * qd + 4 * h);
+      }
+      v4i alo = a[gg], ahi = a[gg];
+      if constexpr (TR::half_scales) {   // Q6_K: separate sums over k < 16 and k >= 16 — zero the other half's lanes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { alo[i] = h == 0 ? a[gg][i] : 0; ahi[i] = h == 1 ? a[gg][i] : 0; }
+      }
 #pragma unroll
       for (int jj = 0; jj < TB; ++jj) {
         const uint32_t dsw = gg ? ds1[jj] : ds0[jj];
-        const float bs = bits_h_f32(dsw & 0xFFFF);
-        const float nmbs = -(MAGIC_F * bs);
-        const v16i c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[gg], B[jj][gg], magic, 0, 0, 0);
-        B[jj][gg] = *(const __attribute__((address_space(1))) v4i*)(abase[jj] + 1024 * gg + lane16);   // refill in place: a full iteration of lead
+        float bs, bm = 0.0f;
+        if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
+        else bs = as_f32((int)dsw);
+        const float nmbs = -(MAGIC_F * bs);   // exact when bs is an fp16 value (need_sum formats)
+        v16i c0, c1 = magic;
+        if constexpr (TR::half_scales) {
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B[jj][gg], magic, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B[jj][gg], magic, 0, 0, 0);
+        } else {
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[gg], B[jj][gg], magic, 0, 0, 0);
+          if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[gg], B[jj][gg], magic, 0, 0, 0);
+        }
+        B[jj][gg] = *(gptr_v4i)(abase[jj] + 1024 * gg + lane16);   // refill in place: a full iteration of lead
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * qd + e;
-            acc[jj][i] = __builtin_fmaf(__builtin_fmaf(as_f32(c0[i]), bs, nmbs), sa[qd][e], acc[jj][i]);
+            const float df0 = as_f32(c0[i]);   // = 12582912 + C exactly
+            const float sae = sa[qd][e];
+            // explicit fma + -ffp-contract=off: every accumulator register sees the same instruction
+            // sequence, so a row's result does not depend on its position in the tile
+            if constexpr (TR::fp16_prod) {   // Q4_1/Q5_1, mmq.cuh:527-529 / :840-842
+              const float lo = (float)((_Float16)sae * (_Float16)bs);
+              const float hi = (float)((_Float16)sbv[qd][e] * (_Float16)bm);
+              acc[jj][i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
+            } else if constexpr (TR::two_tiles) {   // Q2_K: d8 (dall·Σsc q q8 − dmin·Σ m q8), mmq.cuh:47
+              const float df1 = as_f32(c1[i]);
+              acc[jj][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, df0 - MAGIC_F, -(sbv[qd][e] * (df1 - MAGIC_F))), acc[jj][i]);
+            } else if constexpr (TR::half_scales) {   // Q6_K (fp32 d8): mmq.cuh:1726-1732
+              const float df1 = as_f32(c1[i]);
+              acc[jj][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[jj][i]);
+              acc[jj][i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sbv[qd][e], acc[jj][i]);
+            } else if constexpr (TR::need_sum) {   // Q4_0, Q4_K, Q5_K (fp16 d8): float(C)·d8 in one exact fma
+              acc[jj][i] = __builtin_fmaf(__builtin_fmaf(df0, bs, nmbs), sae, acc[jj][i]);
+            } else {   // Q5_0 / Q8_0 / Q3_K (fp32 d8): d_w d8 C
+              acc[jj][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[jj][i]);
+            }
           }
       }
     }
@@ -1218,7 +1348,6 @@ __global__ void __launch_bounds__(256, 3) mmq_stream_kernel(const uint8_t* __res
 
   GGQ_STAMP(2);
   // ---- K-slice reduction (the rings are dead once every wave has passed its last ds_read) ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   float* red = (float*)lds;   // [3][TB][16][64]
   if (ks > 0) {
@@ -1269,21 +1398,18 @@ __global__ void __launch_bounds__(256, 3) mmq_stream_kernel(const uint8_t* __res
 template <int T, int DT, int TB>
 static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                              int64_t ldy, hipStream_t s) {
-  if constexpr (T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K) {
-    constexpr int LDS = 4 * StreamLds<T>::WAVE;
-    static_assert(LDS >= 3 * TB * 16 * 64 * 4, "K-slice reduction aliases the rings");
-    const int64_t n_tok_tiles = (batch + 32 * TB - 1) / (32 * TB);
-    const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
-    if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
-    const int64_t per_xcd = (n_units + 7) / 8;
-    hipLaunchKernelGGL((mmq_stream_kernel<T, DT, TB>), dim3((unsigned)(per_xcd * 8)), dim3(256), LDS, s,
-                       (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy,
-                       (int)n_tok_tiles, (int)n_units, (int)per_xcd);
-    GGQ_HIP_CHECK_LAUNCH();
-    return GGQ_OK;
-  } else {
-    return GGQ_ERR_TYPE;
-  }
+  constexpr int LDS = 4 * StreamCfg<T>::WAVE;
+  static_assert(LDS >= 3 * TB * 16 * 64 * 4, "K-slice reduction aliases the rings");
+  static_assert(LDS * StreamCfg<T>::OCC <= 160 * 1024, "LDS of the resident workgroups");
+  const int64_t n_tok_tiles = (batch + 32 * TB - 1) / (32 * TB);
+  const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
+  if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
+  const int64_t per_xcd = (n_units + 7) / 8;
+  hipLaunchKernelGGL((mmq_stream_kernel<T, DT, TB>), dim3((unsigned)(per_xcd * 8)), dim3(256), LDS, s,
+                     (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy,
+                     (int)n_tok_tiles, (int)n_units, (int)per_xcd);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
 }
 }  // namespace ggq
 
@@ -1293,7 +1419,9 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
                             int64_t n, int64_t ldy, hipStream_t s) {
   // 32-token units while one token tile covers the batch, 64-token units beyond (measured r1, Q4_K
   // 11008x4096: batch 32 14.4 vs 20.0 us, batch 128 38.8 vs 29.9 us)
-  const bool one = batch <= 32;
+  static const char* e = getenv("GGQ_MMQ_TB");   // experiments: force 32- or 64-token units
+  // (Q2_K's second int8 tile does not fit 168 VGPRs with two token blocks: 168 us spilled vs 54 us)
+  const bool one = e ? e[0] == '1' : (batch <= 32 || MmqTraits<T>::two_tiles);
   switch (dt) {
     case GGQ_F32: return one ? launch_mmq_stream<T, GGQ_F32, 1>(w, q8, y, batch, k, n, ldy, s) : launch_mmq_stream<T, GGQ_F32, 2>(w, q8, y, batch, k, n, ldy, s);
     case GGQ_F16: return one ? launch_mmq_stream<T, GGQ_F16, 1>(w, q8, y, batch, k, n, ldy, s) : launch_mmq_stream<T, GGQ_F16, 2>(w, q8, y, batch, k, n, ldy, s);
@@ -1304,7 +1432,7 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
 }  // namespace ggq
 
 extern "C" int ggq_mmq_tiled_supported(int type, int64_t k) {
-  return (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K) && k > 0 && k % 256 == 0;
+  return ggq_type_supported(type) && k > 0 && k % ggq_block_elems(type) == 0;
 }
 
 extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int type, int dtype,
@@ -1319,10 +1447,21 @@ extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int
   if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
   if (n_rows == 0 || batch == 0) return GGQ_OK;
   if (!w || !q || !y) return GGQ_ERR_ARG;
-  if (((uintptr_t)w & 15) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;   // 16-byte row chunks
+  if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  if (type == GGQ_TYPE_Q4_K) return launch_mmq_tiled<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-  return launch_mmq_tiled<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+  switch (type) {
+    case GGQ_TYPE_Q4_0: return launch_mmq_tiled<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q4_1: return launch_mmq_tiled<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q5_0: return launch_mmq_tiled<GGQ_TYPE_Q5_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q5_1: return launch_mmq_tiled<GGQ_TYPE_Q5_1>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q8_0: return launch_mmq_tiled<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q2_K: return launch_mmq_tiled<GGQ_TYPE_Q2_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q3_K: return launch_mmq_tiled<GGQ_TYPE_Q3_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q4_K: return launch_mmq_tiled<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q5_K: return launch_mmq_tiled<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q6_K: return launch_mmq_tiled<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    default: return GGQ_ERR_TYPE;
+  }
 }
 
 extern "C" int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type, int dtype,
@@ -1331,7 +1470,12 @@ extern "C" int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type,
   if (!scratch) return GGQ_ERR_ARG;
   // Q4_K / Q5_K beyond the GEMV-like batches: fragment-major activations + the streamed kernel
   // (batch <= 4 stays on the dot4 kernel: 8.1 / 10.9 us vs 14.2 us at the headline shape)
-  if (ggq_mmq_tiled_supported(type, k) && batch > 4 && ((uintptr_t)w & 15) == 0) {
+  // Measured r1 on 11008 x 4096 (kernel only, us; dot4 / LDS-tile kernel vs streamed):
+  //   Q4_K b8 19.7/16.3  b32 20.4/16.5  b128 40.9/31.3 | Q4_0 b8 18.0/15.4  b128 39.3/30.6
+  //   Q8_0 b8 18.4/25.1  b64 26.5/29.1  b128 42.9/42.3 | Q6_K b16 26.7/28.9  b64 48.0/38.5  b128 73.8/61.5
+  // batch <= 4 stays on the dot4 kernel for every format (Q4_K: 8.1 / 10.9 us at batch 1 / 4 vs 14.2 us).
+  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? 65 : type == GGQ_TYPE_Q6_K ? 33 : 5;
+  if (ggq_mmq_tiled_supported(type, k) && batch >= stream_from) {
     const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
     if (rc != GGQ_OK) return rc;
     return ggq_mul_mat_q_pretiled(w, scratch, y, type, dtype, batch, k, n_rows, ldy, stream);

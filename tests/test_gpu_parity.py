@@ -146,8 +146,8 @@ def test_mmq_vs_oracle(oracle, dtype, t, batch, k, n_rows):
 
 
 @pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q5_0, GGMLType.Q8_0, GGMLType.Q4_1], ids=lambda t: t.name)
-def test_mmq_k_not_multiple_of_256(oracle, t):
-    batch, k, n_rows = 9, 32 * 21, 45
+@pytest.mark.parametrize("batch,k,n_rows", [(9, 32 * 21, 45), (3, 32 * 21, 45), (70, 32 * 5, 33), (40, 32, 64), (33, 32 * 13, 31)])
+def test_mmq_k_not_multiple_of_256(oracle, t, batch, k, n_rows):
     w = synth.random_weight(t, n_rows, k, seed=8)
     x = _x((batch, k), torch.float32, seed=6)
     y = util.gpu_mmq(w, x, t, n_rows)
@@ -155,7 +155,7 @@ def test_mmq_k_not_multiple_of_256(oracle, t):
     util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"mmq {t.name}")
 
 
-STREAM_TYPES = [GGMLType.Q4_K, GGMLType.Q5_K]
+STREAM_TYPES = WEIGHT_TYPES
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
@@ -183,24 +183,26 @@ def test_mmq_streamed_ldy_and_errors(oracle):
     ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
     util.assert_fp_accumulate(y[:, :n_rows], ref, yabs, torch.float16, "streamed mmq ldy")
     assert torch.count_nonzero(y[:, n_rows:]) == 0, "columns beyond n_rows were written"
-    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q4_0), 4096) == 0
-    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q8_0), 4096) == 0
+    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q4_0), 4096) == 1
+    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q4_K), 4096 + 32) == 0
+    assert L.ggq_mmq_tiled_supported(1, 4096) == 0
     q = torch.zeros(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
     wd = util.dev_bytes(w)
     st = util.stream_ptr()
-    assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(GGMLType.Q8_0), 1, batch, k, n_rows, ldy, st) == -1
+    assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), 1, 1, batch, k, n_rows, ldy, st) == -1
     assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(t), 7, batch, k, n_rows, ldy, st) == -3
     assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(t), 1, batch, k, n_rows, n_rows - 1, st) == -4
-    assert L.ggq_mul_mat_q_pretiled(ctypes.c_void_p(wd.data_ptr() + 2), util.vp(q), util.vp(y), int(t), 1, batch, k, n_rows, ldy, st) == -6
+    assert L.ggq_mul_mat_q_pretiled(ctypes.c_void_p(wd.data_ptr() + 1), util.vp(q), util.vp(y), int(t), 1, batch, k, n_rows, ldy, st) == -6
     assert L.ggq_mul_mat_q_pretiled(util.vp(wd), util.vp(q), util.vp(y), int(t), 1, 0, k, n_rows, ldy, st) == 0
     assert L.ggq_quantize_q8_1_tiled(util.vp(x), 1, ctypes.c_void_p(q.data_ptr() + 4), batch, k, int(t), st) == -6
 
 
-def test_mmq_weight_pointer_not_16_aligned(oracle):
-    """GGUF tensors are 32-byte aligned, but the ABI only asks for 2: the fused op must fall back to the
-    reference-layout kernel for an odd weight pointer and still agree with the oracle."""
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q6_K, GGMLType.Q8_0], ids=lambda t: t.name)
+def test_mmq_weight_pointer_not_16_aligned(oracle, t):
+    """GGUF tensors are 32-byte aligned, but the ABI only asks for 2: the 16-byte row chunks of the streamed
+    kernel must work from any even address."""
     L = ggqlib.hip()
-    t, batch, k, n_rows = GGMLType.Q4_K, 40, 512, 48
+    batch, k, n_rows = 40, 512, 48
     w = synth.random_weight(t, n_rows, k, seed=6)
     x = _x((batch, k), torch.float32, seed=16)
     buf = torch.zeros(w.size + 64, dtype=torch.uint8, device="cuda")
@@ -212,7 +214,7 @@ def test_mmq_weight_pointer_not_16_aligned(oracle):
                                  n_rows, util.vp(scratch), util.stream_ptr()), "ggq_mul_mat_q")
     torch.cuda.synchronize()
     ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
-    util.assert_fp_accumulate(y, ref, yabs, torch.float32, "mmq unaligned w")
+    util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"mmq unaligned w {t.name}")
 
 
 def test_mmq_integer_exact(oracle):
