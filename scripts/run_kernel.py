@@ -1,5 +1,5 @@
 """Run one hot-path kernel a few times (for rocprofv3 --pmc / --kernel-trace runs).
-usage: python scripts/run_kernel.py {mmq|mmvq|dequant|quant} [type] [batch] [iters]"""
+usage: python scripts/run_kernel.py {mmq|mmq_ref_layout|mmvq|dequant|quant} [type] [batch] [iters]"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ggml-libtorch_amd"))
@@ -18,10 +18,14 @@ x = torch.randn((batch, K), generator=torch.Generator().manual_seed(0)).half().c
 y = torch.empty((batch, N), dtype=torch.float16, device="cuda")
 out = torch.empty((N, K), dtype=torch.float16, device="cuda")
 scr = torch.empty(int(L.ggq_mmq_scratch_bytes(batch, K)) + 4096, dtype=torch.uint8, device="cuda")
-if what == "mmq":
+if what == "mmq":   # the kernel ggq_mul_mat_q runs for this (type, batch): streamed kernel on the fragment-major scratch
+    L.ggq_quantize_q8_1_tiled(vp(x), 1, vp(scr), batch, K, t, st())
+elif what == "mmq_ref_layout":
     L.ggq_quantize_q8_1_mmq(vp(x), 1, vp(scr), batch, K, t, st())
 for _ in range(iters):
     if what == "mmq":
+        L.ggq_mul_mat_q_pretiled(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, st())
+    elif what == "mmq_ref_layout":
         L.ggq_mul_mat_q_prequant(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, st())
     elif what == "mmvq":
         L.ggq_mul_mat_vec_q(vp(w), vp(x), vp(y), t, 1, K, N, vp(scr), st())
