@@ -20,6 +20,21 @@
 //     64-lane shuffle reduction at the end of each row.
 #include "ggq_common.h"
 
+#ifndef GGQ_MMVQ_UNROLL
+#define GGQ_MMVQ_UNROLL 1
+#endif
+#ifndef GGQ_MMVQ_ROWS
+#define GGQ_MMVQ_ROWS 2   // rows in flight per wave in the fused kernel
+#endif
+
+#if defined(GGQ_VSTAMP)
+__device__ unsigned long long g_vstamps[8192 * 8];
+extern "C" int ggq_debug_read_vstamps(void* dst, long long n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vstamps), n * 8); }
+#define VSTAMP(i) do { if ((threadIdx.x & 63) == 0) g_vstamps[((blockIdx.x * 16 + (threadIdx.x >> 6)) & 8191) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define VSTAMP(i) do {} while (0)
+#endif
+
 namespace ggq {
 
 struct ActLds {
@@ -265,8 +280,11 @@ template <> struct UnitDot<GGQ_TYPE_Q6_K> {  // vecdotq.cuh:327-345, 587-605
 // LDS bytes for a row of k activations: int8[k] + float[k/32]*2 + int[k/16]
 static inline size_t mmvq_lds_bytes(int64_t k) { return (size_t)k + (size_t)(k / 32) * 8 + (size_t)(k / 16) * 4; }
 
-template <int T, int DT, int ROWS>
-__global__ void __launch_bounds__(256) mmvq_kernel(const uint8_t* __restrict__ w,
+// FUSED: q8 is the activation row itself (dtype DT); every workgroup quantises it into LDS with the
+// arithmetic of quantize.hip (bit-identical d, q, sum) while its first weight bytes are in flight —
+// one launch instead of two (the second launch cost 2.3 of 8.8 us at the headline shape).
+template <int T, int DT, int ROWS, bool FUSED>
+__global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t* __restrict__ w,
                                                    const uint8_t* __restrict__ q8,
                                                    void* __restrict__ y, int k, int n_rows,
                                                    int rows_per_wave) {
@@ -275,19 +293,70 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const uint8_t* __restrict__ w
   float* xd = (float*)(lds + k);
   float* xs = xd + k / 32;
   int* xi16 = (int*)(xs + k / 32);
+  const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
 
-  // ---- stage the Q8_1 row: block_q8_1 {half d, half s, int8 qs[32]} -> de-interleaved ----
-  for (int i = threadIdx.x; i < k / 4; i += 256) {
-    const int g = i >> 3, j = i & 7;
-    ((uint32_t*)xq)[i] = *(const uint32_t*)(q8 + (int64_t)g * 36 + 4 + 4 * j);
+  uint32_t touch = 0;
+  VSTAMP(0);
+  if constexpr (FUSED) {
+    // start the HBM fetch of this wave's first ROWS rows (contiguous bytes) before the quantisation below
+    // (fused launches use 16-wave workgroups, one per CU, and split the rows evenly over all waves:
+    //  every workgroup repeats the quantisation, so there must be few of them)
+    const int n_waves = gridDim.x * 16, wave0 = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const int r0 = (int)((int64_t)wave0 * n_rows / n_waves);
+    const int64_t span = (int64_t)((int)((int64_t)(wave0 + 1) * n_rows / n_waves) - r0) * row_bytes;
+    const uint8_t* p = w + (int64_t)r0 * row_bytes;
+
+    // ---- quantise x -> Q8_1 in LDS: lane = 4 elements, 8 lanes = one 32-group (quantize.hip).  The first
+    //      x loads are issued before the weight touches: vector loads return in order, and x (8 KB, L2-hot
+    //      after the first workgroup) must not queue behind this wave's HBM misses. ----
+    float v[4];
+    if (threadIdx.x * 4 < k) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld(q8, threadIdx.x * 4 + i);
+    }
+    for (int64_t o = (threadIdx.x & 63) * 64; o < span; o += 4096) touch += p[o];
+    for (int ix = threadIdx.x * 4; ix < k; ix += 4096) {   // k % 32 == 0: a group is never split
+      if (ix != (int)threadIdx.x * 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld(q8, ix + i);
+      }
+      float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+      float sm[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int m = 4; m > 0; m >>= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm[i] = sm[i] + __shfl_xor(sm[i], m, 64);
+      const float sum = (sm[0] + sm[2]) + (sm[1] + sm[3]);
+      const float d = amax / 127;
+      int qi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qi[i] = amax == 0.0f ? 0 : (int)roundf(v[i] / d);
+      ((uint32_t*)xq)[ix >> 2] = (uint32_t)(qi[0] & 0xFF) | ((uint32_t)(qi[1] & 0xFF) << 8) |
+                                 ((uint32_t)(qi[2] & 0xFF) << 16) | ((uint32_t)(qi[3] & 0xFF) << 24);
+      if ((ix & 31) == 0) {   // block_q8_1 stores half d, half sum: keep their fp16 rounding
+        xd[ix >> 5] = (float)(_Float16)d;
+        xs[ix >> 5] = (float)(_Float16)sum;
+      }
+    }
+  } else {
+    // ---- stage the Q8_1 row: block_q8_1 {half d, half s, int8 qs[32]} -> de-interleaved ----
+    for (int i = threadIdx.x; i < k / 4; i += 256) {
+      const int g = i >> 3, j = i & 7;
+      ((uint32_t*)xq)[i] = *(const uint32_t*)(q8 + (int64_t)g * 36 + 4 + 4 * j);
+    }
+    for (int g = threadIdx.x; g < k / 32; g += 256) {
+      const uint32_t ds = *(const uint32_t*)(q8 + (int64_t)g * 36);
+      xd[g] = bits_h_f32(ds & 0xFFFF);
+      xs[g] = bits_h_f32(ds >> 16);
+    }
   }
-  for (int g = threadIdx.x; g < k / 32; g += 256) {
-    const uint32_t ds = *(const uint32_t*)(q8 + (int64_t)g * 36);
-    xd[g] = bits_h_f32(ds & 0xFFFF);
-    xs[g] = bits_h_f32(ds >> 16);
-  }
+  VSTAMP(1);
   __syncthreads();
-  for (int i = threadIdx.x; i < k / 16; i += 256) {
+  VSTAMP(2);
+  for (int i = threadIdx.x; i < k / 16; i += (FUSED ? 1024 : 256)) {
     const v4i a = *(const v4i*)(xq + 16 * i);
     int s = sdot4(0x01010101, a[0], 0);
     s = sdot4(0x01010101, a[1], s);
@@ -298,20 +367,34 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const uint8_t* __restrict__ w
   const ActLds A{xq, xd, xs, xi16};
 
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = blockIdx.x * (FUSED ? 16 : 4) + (threadIdx.x >> 6);
   const int units = k / Fmt<T>::QK * UnitDot<T>::UPB;
-  const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
-  const int row_end = min(n_rows, (wave + 1) * rows_per_wave);
+  int row_begin, row_end;
+  if constexpr (FUSED) {
+    const int n_waves = gridDim.x * 16;
+    row_begin = (int)((int64_t)wave * n_rows / n_waves);
+    row_end = (int)((int64_t)(wave + 1) * n_rows / n_waves);
+  } else {
+    row_begin = wave * rows_per_wave;
+    row_end = min(n_rows, (wave + 1) * rows_per_wave);
+  }
+  asm volatile("" ::"v"(touch));
+  VSTAMP(3);
 
-  for (int r0 = wave * rows_per_wave; r0 < row_end; r0 += ROWS) {
+  for (int r0 = row_begin; r0 < row_end; r0 += ROWS) {
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+#pragma unroll GGQ_MMVQ_UNROLL
     for (int u = lane; u < units; u += 64) {
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-        const int row = min(r0 + r, n_rows - 1);  // clamp: duplicate work, never out of bounds
-        acc[r] += UnitDot<T>::run(w + row * row_bytes, u, A);
+        if constexpr (FUSED) {   // wave-uniform: a short last group simply skips the row
+          if (r0 + r < row_end) acc[r] += UnitDot<T>::run(w + (int64_t)(r0 + r) * row_bytes, u, A);
+        } else {
+          const int row = min(r0 + r, n_rows - 1);  // clamp: duplicate work, never out of bounds
+          acc[r] += UnitDot<T>::run(w + row * row_bytes, u, A);
+        }
       }
     }
 #pragma unroll
@@ -320,11 +403,12 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const uint8_t* __restrict__ w
       if (lane == 0 && r0 + r < row_end) Elem<DT>::st(y, r0 + r, tot);
     }
   }
+  VSTAMP(4);
 }
 
-template <int T, int DT>
+template <int T, int DT, bool FUSED>
 static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int64_t n, hipStream_t s) {
-  constexpr int ROWS = 2;
+  constexpr int ROWS = FUSED ? GGQ_MMVQ_ROWS : 2;
   const size_t lds = mmvq_lds_bytes(k);
   if (lds > 160 * 1024) return GGQ_ERR_SHAPE;
   // many short-lived waves keep more weight bytes in flight (measured: 2 rows per wave beats
@@ -333,25 +417,46 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
   rpw = rpw < ROWS ? ROWS : (rpw > 16 ? 16 : rpw);
   rpw = (rpw + ROWS - 1) / ROWS * ROWS;
   const int64_t waves = (n + rpw - 1) / rpw;
-  const int64_t grid = (waves + 3) / 4;
-  auto kern = mmvq_kernel<T, DT, ROWS>;
+  int64_t grid = (waves + 3) / 4;
+  if (FUSED) {   // one 16-wave workgroup per CU (fewer when there are fewer than 2 rows per wave)
+    grid = (n + 31) / 32;
+    grid = grid > 256 ? 256 : grid;
+  }
+  auto kern = mmvq_kernel<T, DT, ROWS, FUSED>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GGQ_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, (const uint8_t*)w,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FUSED ? 1024 : 256), lds, s, (const uint8_t*)w,
                      (const uint8_t*)q8, y, (int)k, (int)n, rpw);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }
 
 template <int T>
-static int launch_mmvq(const void* w, const void* q8, void* y, int dt, int64_t k, int64_t n, hipStream_t s) {
+static int launch_mmvq(const void* w, const void* q8, void* y, int dt, int64_t k, int64_t n, bool fused, hipStream_t s) {
   switch (dt) {
-    case GGQ_F32: return launch_mmvq_t<T, GGQ_F32>(w, q8, y, k, n, s);
-    case GGQ_F16: return launch_mmvq_t<T, GGQ_F16>(w, q8, y, k, n, s);
-    case GGQ_BF16: return launch_mmvq_t<T, GGQ_BF16>(w, q8, y, k, n, s);
+    case GGQ_F32: return fused ? launch_mmvq_t<T, GGQ_F32, true>(w, q8, y, k, n, s) : launch_mmvq_t<T, GGQ_F32, false>(w, q8, y, k, n, s);
+    case GGQ_F16: return fused ? launch_mmvq_t<T, GGQ_F16, true>(w, q8, y, k, n, s) : launch_mmvq_t<T, GGQ_F16, false>(w, q8, y, k, n, s);
+    case GGQ_BF16: return fused ? launch_mmvq_t<T, GGQ_BF16, true>(w, q8, y, k, n, s) : launch_mmvq_t<T, GGQ_BF16, false>(w, q8, y, k, n, s);
     default: return GGQ_ERR_DTYPE;
+  }
+}
+
+static int mmvq_dispatch(const void* w, const void* q, void* y, int type, int dtype, int64_t k, int64_t n_rows,
+                         bool fused, hipStream_t s) {
+  switch (type) {
+    case GGQ_TYPE_Q4_0: return launch_mmvq<GGQ_TYPE_Q4_0>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q4_1: return launch_mmvq<GGQ_TYPE_Q4_1>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q5_0: return launch_mmvq<GGQ_TYPE_Q5_0>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q5_1: return launch_mmvq<GGQ_TYPE_Q5_1>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q8_0: return launch_mmvq<GGQ_TYPE_Q8_0>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q2_K: return launch_mmvq<GGQ_TYPE_Q2_K>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q3_K: return launch_mmvq<GGQ_TYPE_Q3_K>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q4_K: return launch_mmvq<GGQ_TYPE_Q4_K>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q5_K: return launch_mmvq<GGQ_TYPE_Q5_K>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, fused, s);
+    default: return GGQ_ERR_TYPE;
   }
 }
 
@@ -368,26 +473,26 @@ extern "C" int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y,
   if (n_rows == 0) return GGQ_OK;
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 3)) return GGQ_ERR_ALIGN;
-  hipStream_t s = (hipStream_t)stream;
-  switch (type) {
-    case GGQ_TYPE_Q4_0: return launch_mmvq<GGQ_TYPE_Q4_0>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q4_1: return launch_mmvq<GGQ_TYPE_Q4_1>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q5_0: return launch_mmvq<GGQ_TYPE_Q5_0>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q5_1: return launch_mmvq<GGQ_TYPE_Q5_1>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q8_0: return launch_mmvq<GGQ_TYPE_Q8_0>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q2_K: return launch_mmvq<GGQ_TYPE_Q2_K>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q3_K: return launch_mmvq<GGQ_TYPE_Q3_K>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q4_K: return launch_mmvq<GGQ_TYPE_Q4_K>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q5_K: return launch_mmvq<GGQ_TYPE_Q5_K>(w, q, y, dtype, k, n_rows, s);
-    case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, s);
-    default: return GGQ_ERR_TYPE;
-  }
+  return mmvq_dispatch(w, q, y, type, dtype, k, n_rows, false, (hipStream_t)stream);
 }
 
 extern "C" int ggq_mul_mat_vec_q(const void* w, const void* x, void* y, int type, int dtype,
                                  int64_t k, int64_t n_rows, void* scratch, void* stream) {
-  if (!scratch) return GGQ_ERR_ARG;
-  int rc = ggq_quantize_q8_1(x, dtype, scratch, 1, k, stream);
-  if (rc != GGQ_OK) return rc;
-  return ggq_mul_mat_vec_q_prequant(w, scratch, y, type, dtype, k, n_rows, stream);
+  using namespace ggq;
+  if (!scratch) return GGQ_ERR_ARG;   // kept in the signature (reference: quant_X), unused by the fused kernel
+  if (k <= 0 || n_rows < 0) return GGQ_ERR_ARG;
+  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
+  if (k > 0x7fffffffLL / 64 || n_rows > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (n_rows == 0) return GGQ_OK;
+  if (!w || !x || !y) return GGQ_ERR_ARG;
+  if ((uintptr_t)w & 1) return GGQ_ERR_ALIGN;
+  static const char* e = getenv("GGQ_MMVQ_FUSED");   // 0: two launches (quantize_q8_1 + mul_mat_vec_q), for comparison
+  if (e && e[0] == '0') {
+    const int rc = ggq_quantize_q8_1(x, dtype, scratch, 1, k, stream);
+    if (rc != GGQ_OK) return rc;
+    return ggq_mul_mat_vec_q_prequant(w, scratch, y, type, dtype, k, n_rows, stream);
+  }
+  return mmvq_dispatch(w, x, y, type, dtype, k, n_rows, true, (hipStream_t)stream);
 }
