@@ -1,7 +1,7 @@
 """The drop-in operator surface on the GPU: written to read like the reference's own
 tests (HK/tests/kernels/test_cuda_kernels.py) — same calls, same tolerances — with the
-GGUF sample files replaced by synthetic block-valid tensors and gguf.dequantize by its
-numpy restatement (oracle/ggq_numpy.py)."""
+GGUF sample files written locally (synthetic block-valid tensors, ggq.gguf_io) and read back
+with our GGUF reader, and gguf.dequantize replaced by its numpy restatement (oracle/ggq_numpy.py)."""
 import numpy as np
 import pytest
 import torch
@@ -18,13 +18,33 @@ NUM_TOKENS = [7, 83, 128, 2048]
 QUANT_TYPES = WEIGHT_TYPES  # the reference lists Q2_K..Q6_K, Q4_0, Q5_0, Q8_0; Q4_1/Q5_1 added
 
 
+_SAMPLE_DIR = None
+
+
+def get_gguf_sample_tensors(hidden_size, quant_type):
+    """benchmarks/utils.py:25-31 / HK/tests/utils.py:25-31 with the HF-hub download replaced by a locally
+    written `Quant_{TYPE}_{hidden}.gguf` (ggq.gguf_io.write_sample_file) and gguf.GGUFReader by ours.
+    The reference's absolute tolerances (atol = 1) are tuned to its sample checkpoints, so the K-quant
+    block scales are shrunk until |w| <~ 1 like a real tensor (the default recipe reaches |w| ~ 16)."""
+    global _SAMPLE_DIR
+    import os, tempfile
+    from ggq import gguf_io
+    if _SAMPLE_DIR is None:
+        _SAMPLE_DIR = tempfile.mkdtemp(prefix="ggq_gguf_samples_")
+    path = os.path.join(_SAMPLE_DIR, gguf_io.sample_filename(quant_type, hidden_size))
+    if not os.path.exists(path):
+        d_scale = 2.0 ** -4 if int(quant_type) >= 10 else 1.0
+        gguf_io.write_sample_file(_SAMPLE_DIR, quant_type, hidden_size, seed=hidden_size, d_scale=d_scale,
+                                  row_multiples=(1,))
+    return gguf_io.GGUFReader(path).tensors
+
+
 def sample_tensors(hidden_size, quant_type):
-    """stand-in for get_gguf_sample_tensors: a few [rows, hidden] tensors.  The reference's
-    absolute tolerances (atol = 1) are tuned to its sample checkpoints, so the K-quant block
-    scales are shrunk until |w| <~ 1 like a real tensor (the default recipe reaches |w| ~ 16)."""
+    """(rows, uint8 [rows, row_bytes]) per tensor of the sample file, plus one ragged 96-row tensor"""
+    out = [(t.data.shape[0], np.array(t.data)) for t in get_gguf_sample_tensors(hidden_size, quant_type)]
     d_scale = 2.0 ** -4 if int(quant_type) >= 10 else 1.0
-    return [(rows, synth.random_weight(quant_type, rows, hidden_size, seed=rows, d_scale=d_scale))
-            for rows in (hidden_size, 96)]
+    out.append((96, synth.random_weight(quant_type, 96, hidden_size, seed=96, d_scale=d_scale)))
+    return out
 
 
 @pytest.fixture(scope="module")
