@@ -1073,8 +1073,9 @@ template <int T> struct StreamCfg {
   static constexpr int OCC = TR::half_scales ? 2 : 3;
 };
 
-template <int T, int DT, int TB>
-__global__ void __launch_bounds__(256, StreamCfg<T>::OCC) mmq_stream_kernel(const uint8_t* __restrict__ w,
+// KS = K-slices = waves per workgroup: 4 normally; 8 when there are too few units to give every SIMD three waves
+template <int T, int DT, int TB, int KS>
+__global__ void __launch_bounds__(64 * KS, KS == 4 ? StreamCfg<T>::OCC : 1) mmq_stream_kernel(const uint8_t* __restrict__ w,
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
                                                             int64_t ldy, int n_tok_tiles, int n_units, int per_xcd) {
@@ -1093,7 +1094,7 @@ __global__ void __launch_bounds__(256, StreamCfg<T>::OCC) mmq_stream_kernel(cons
   const uint32_t row_bytes = (uint32_t)(k / C::QK) * C::BS;
   const int n_groups = k / 32;
   const int n_st = (k + C::SE - 1) / C::SE;
-  const int st_begin = (int)((int64_t)ks * n_st / 4), st_end = (int)((int64_t)(ks + 1) * n_st / 4);
+  const int st_begin = (int)((int64_t)ks * n_st / KS), st_end = (int)((int64_t)(ks + 1) * n_st / KS);
   uint8_t* ring = lds + ks * C::WAVE;
   float* sb = (float*)(ring + 2 * STAGE);
   const int n_tt32 = (batch + 31) / 32;
@@ -1349,7 +1350,7 @@ __global__ void __launch_bounds__(256, StreamCfg<T>::OCC) mmq_stream_kernel(cons
   GGQ_STAMP(2);
   // ---- K-slice reduction (the rings are dead once every wave has passed its last ds_read) ----
   __syncthreads();
-  float* red = (float*)lds;   // [3][TB][16][64]
+  float* red = (float*)lds;   // [KS - 1][TB][16][64]
   if (ks > 0) {
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj)
@@ -1360,7 +1361,7 @@ __global__ void __launch_bounds__(256, StreamCfg<T>::OCC) mmq_stream_kernel(cons
   GGQ_STAMP(3);
   if (ks != 0) return;
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < KS - 1; ++s)
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj)
 #pragma unroll
@@ -1395,21 +1396,43 @@ __global__ void __launch_bounds__(256, StreamCfg<T>::OCC) mmq_stream_kernel(cons
   GGQ_STAMP(4);
 }
 
-template <int T, int DT, int TB>
-static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
-                             int64_t ldy, hipStream_t s) {
-  constexpr int LDS = 4 * StreamCfg<T>::WAVE;
-  static_assert(LDS >= 3 * TB * 16 * 64 * 4, "K-slice reduction aliases the rings");
-  static_assert(LDS * StreamCfg<T>::OCC <= 160 * 1024, "LDS of the resident workgroups");
-  const int64_t n_tok_tiles = (batch + 32 * TB - 1) / (32 * TB);
-  const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
-  if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
+template <int T, int DT, int TB, int KS>
+static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
+                                int64_t ldy, int64_t n_tok_tiles, int64_t n_units, hipStream_t s) {
+  constexpr int LDS = KS * StreamCfg<T>::WAVE;
+  static_assert(LDS >= (KS - 1) * TB * 16 * 64 * 4, "K-slice reduction aliases the rings");
+  static_assert(LDS * (KS == 4 ? StreamCfg<T>::OCC : 1) <= 160 * 1024, "LDS of the resident workgroups");
+  auto kern = mmq_stream_kernel<T, DT, TB, KS>;
+  if (LDS > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
+      attr_set = true;
+    }
+  }
   const int64_t per_xcd = (n_units + 7) / 8;
-  hipLaunchKernelGGL((mmq_stream_kernel<T, DT, TB>), dim3((unsigned)(per_xcd * 8)), dim3(256), LDS, s,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(64 * KS), LDS, s,
                      (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy,
                      (int)n_tok_tiles, (int)n_units, (int)per_xcd);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
+}
+
+template <int T, int DT, int TB>
+static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
+                             int64_t ldy, hipStream_t s) {
+  const int64_t n_tok_tiles = (batch + 32 * TB - 1) / (32 * TB);
+  const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
+  if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
+  // At most one unit per CU (down-projection shapes: 4096 rows x 128 tokens = 256 units): eight K-slices per unit,
+  // so every SIMD still hosts two waves (K = 11008, N = 4096, batch 128: 40.1 -> 32.5 us).  The 235-VGPR
+  // eight-wave workgroup is one per CU, so with more units than CUs it would need a second round (344 units:
+  // 15.6 -> 18.2 us) and the four-slice form stays.
+  static const char* e = getenv("GGQ_MMQ_KS");
+  const int64_t n_st = (k + StreamCfg<T>::SE - 1) / StreamCfg<T>::SE;
+  const bool ks8 = e ? e[0] == '8' : (n_units <= 256 && n_st >= 16);
+  if (ks8) return launch_mmq_stream_ks<T, DT, TB, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+  return launch_mmq_stream_ks<T, DT, TB, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
 }
 }  // namespace ggq
 

@@ -255,6 +255,20 @@ def test_mmq_full_size_rows_sample(oracle, t):
     assert torch.equal(y2, y[:, torch.from_numpy(perm).cuda()])
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q5_1], ids=lambda t: t.name)
+def test_mmq_transposed_shape_rows_sample(oracle, t):
+    """SURVEY §8 secondary shape: K = 11008 (11008 % 512 = 256 exercises the scratch padding; 43 / 86 K stages
+    split unevenly over the four K-slices), N = 4096, batch 128 and a ragged 77."""
+    n_rows, k = 4096, 11008
+    w = synth.random_weight(t, n_rows, k, seed=31)
+    rows = np.r_[0:24, 2000:2024, n_rows - 24:n_rows]
+    for batch in (128, 77):
+        x = _x((batch, k), torch.float16, seed=32)
+        y = util.gpu_mmq(w, x, t, n_rows)
+        ref, yabs = oracle.mul_mat_q(w[rows], x.float().cpu().numpy(), t, len(rows))
+        util.assert_fp_accumulate(y[:, torch.from_numpy(rows).cuda()], ref, yabs, torch.float16, f"mmq transposed {t.name} b={batch}")
+
+
 @pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q4_K], ids=lambda t: t.name)
 def test_mmvq_full_size(oracle, t):
     """BASELINE config 3 shape: batch 1, K=4096, N=11008."""
