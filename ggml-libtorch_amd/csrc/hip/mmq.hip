@@ -12,29 +12,27 @@
 // same factors (fp16 products for Q4_1/Q5_1, fp16 d8/s8 for need_sum formats, fp32 d8
 // otherwise, s8 — not d8·Σq8 — for the Q4_K/Q5_K min term); fp32 accumulation order ours.
 //
-// Structure (v2).  The kernel is VALU-bound, not MFMA- or HBM-bound: every (row, token,
-// 32-group) triple needs its own float scale, so the design minimises vector ops per triple.
-//   * workgroup = 512 threads = 8 waves = TBn token-blocks x (8/TBn) K-slices; workgroup tile
-//     ("unit") = 32 weight rows x 32·TBn tokens over all of K; one unit per workgroup, the
-//     hardware dispatcher balances the 2.7 units/CU of the headline shape;
-//   * K is walked in 256-element slabs; a slab's 8 groups are split over the K-slice waves, so
-//     each SIMD hosts two waves of the same tile (full VALU issue rate) and the K-slice partial
-//     sums are combined once per unit through LDS;
-//   * weights: global -> registers (prefetched two slabs ahead) -> unpacked to signed int8 in a
-//     double-buffered LDS tile ([row][256+16 pad]: conflict-free ds_read_b128 A fragments), with
-//     per-(group,row) float scales laid out [group][row] for broadcast ds_read_b128;
-//   * activations: block_q8_1_mmq scratch copied verbatim (16-B accesses, register prefetch two
-//     slabs ahead); its 144-byte token pitch is conflict-free for the B-fragment ds_read_b128;
+// Three kernels, all VALU-issue-bound rather than MFMA- or HBM-bound (every (row, token, 32-group) triple needs
+// its own float scale: 2 vector ops per triple, 3 with an fp32 d8):
+//   mmq_stream_kernel  what ggq_mul_mat_q runs from batch 5 (Q6_K: 33, Q8_0: 65) on the fragment-major scratch:
+//                      no workgroup barrier in the K loop (see its header comment);
+//   mmq_kernel         barrier-coupled LDS-tile kernel on the reference-layout scratch (ggq_mul_mat_q_prequant,
+//                      and the mid-size batches of Q6_K / Q8_0): 8 waves = TBn token blocks x (8/TBn) K-slices per
+//                      256-element slab; weights global -> registers -> unpacked int8 LDS tile ([row][256+16]:
+//                      conflict-free ds_read_b128), activations by LDS-DMA, one barrier per slab;
+//   mmq_small_kernel   batch <= 8, HBM-bound regime: dot4 against LDS-resident activations, no MFMA tiles.
+// Shared by all three:
 //   * per group: v_mfma_i32_32x32x32_i8 with the accumulator input preset to 0x4B400000, so the
 //     int32 result read as a float is 12582912 + C exactly — no v_cvt; for fp16 activation scales
 //     (need_sum formats) one fma(Df, d8, -12582912·d8) yields float(C)·d8 bit-exactly, a second
-//     fma applies the row scale: 2 vector ops per triple (3 with an fp32 d8);
-//   * Q4_K/Q5_K min term Σ m·s8 runs on the otherwise idle matrix pipe: one
-//     v_mfma_f32_32x32x2_f32 per group pair accumulates straight into the fp32 accumulators.
+//     fma applies the row scale;
+//   * Q4_K/Q5_K min term Σ m·s8 runs on the matrix pipe: one v_mfma_f32_32x32x2_f32 per group pair
+//     accumulates straight into the fp32 accumulators;
+//   * unpack_raw<T>: one definition of the integer operands and float scales per format (MMQ canon).
 #include "ggq_common.h"
 
 #ifndef GGQ_ABL
-#define GGQ_ABL 0   // kernel ablation switches (experiments only; 0 in every shipped build)
+#define GGQ_ABL 0   // 32: per-wave timestamps in the streamed kernel (scripts/stamps_mmq.py); 0 in every shipped build
 #endif
 
 #if GGQ_ABL & 32
@@ -488,293 +486,6 @@ __global__ void __launch_bounds__(512, MmqTraits<T>::light && TBn <= 2 ? 4 : 2) 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Warp-specialised kernel for the 64-token unit (32 weight rows x 64 tokens): 12 waves.
-//   waves 0-7   consumers.  K is walked in 512-element slabs (16 groups = four 128-element blocks);
-//               consumer (tb = w & 1, kq = w >> 1) owns block kq of every slab for token block tb:
-//               four tile-groups between two barriers (with two, the LDS + MFMA latency exposed
-//               at every barrier cost as much as the work).  Per tile-group: one int8 MFMA + two
-//               FMAs per triple; the Q4_K/Q5_K min term is two v_mfma_f32_32x32x2_f32 per slab.
-//               Consumers also issue the LDS-DMA (4-5 instructions per slab each) that streams the
-//               activation slab two slabs ahead into a 3-deep ring.
-//   waves 8-11  weight producers: global -> registers (two slabs ahead) -> signed int8 tile + float
-//               scales in a double-buffered LDS stage; thread = (row, group) and (row, group + 8).
-// One s_barrier per slab.  Each SIMD hosts two consumers and one producer.  153.6 KB LDS, one
-// workgroup per CU; the dispatcher balances the 2.7 units per CU of the headline shape.
-// ---------------------------------------------------------------------------------------------
-constexpr int WROW2 = 528;   // LDS pitch of one unpacked 512-element weight row (+16: conflict-free)
-constexpr int SPITCH = 36;   // floats per group in the scale arrays (32 rows + 4: conflict-free writes)
-
-template <int T> struct MmqWsLds {
-  static constexpr int TT = 64;
-  static constexpr int W_TILE = 32 * WROW2;
-  static constexpr int S_ARR = 16 * SPITCH * 4;            // one scale array (bytes)
-  static constexpr int WS_STAGE = W_TILE + MmqTraits<T>::n_scale * S_ARR;
-  static constexpr int A_BYTES = 4 * TT * 144;             // activations of one 512-element slab
-  static constexpr int W_OFF = 0;                          // 2 stages
-  static constexpr int A_OFF = 2 * WS_STAGE;               // 3 stages
-  static constexpr int BYTES = A_OFF + 3 * A_BYTES;
-  static constexpr int N_INSTR = 4 * TT * 9 / 64;          // 36 DMA instructions per slab
-  static constexpr int N_DMA = (N_INSTR + 7) / 8;          // 5 per consumer wave, the 5th on waves 0-3 only
-};
-
-template <int T, int DT>
-__global__ void __launch_bounds__(768) mmq_ws_kernel(const uint8_t* __restrict__ w,
-                                                     const uint8_t* __restrict__ q8,
-                                                     void* __restrict__ y, int k, int n_rows, int batch,
-                                                     int64_t ldy, int n_tok_tiles) {
-  using L = MmqWsLds<T>;
-  using TR = MmqTraits<T>;
-  static_assert(!TR::two_tiles, "Q2_K keeps the generic kernel (second int8 tile does not fit)");
-  constexpr int TT = 64;
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int unit = blockIdx.x;
-  const int n0 = (unit / n_tok_tiles) * 32;
-  const int t0 = (unit % n_tok_tiles) * TT;
-  const int n_valid_tok = min(TT, batch - t0);
-  const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
-  const int n_groups = k / 32;
-  const int n_slabs = (k + 511) / 512;
-
-  if (wave >= 8) {
-    // ================= weight producer =================
-    const int ptid = tid - 512;                 // 0..255
-    const int sr = ptid >> 3, sg = ptid & 7;    // row; groups sg and sg + 8 of the slab
-    const uint8_t* srow = w + (int64_t)min(n0 + sr, n_rows - 1) * row_bytes;
-    auto load2 = [&](Raw (&R)[2], int s) {
-      const int sc = min(s, n_slabs - 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        load_raw<T>(srow, min(sc * 16 + sg + 8 * j, n_groups - 1), R[j]);  // clamped, never predicated
-    };
-    auto write2 = [&](const Raw (&R)[2], int s) {
-      uint8_t* st = lds + L::W_OFF + (s & 1) * L::WS_STAGE;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        uint32_t wq[8], wq2[8];
-        float s0 = 0.0f, s1 = 0.0f;
-        const int G = s * 16 + sg + 8 * j;
-        unpack_raw<T>(R[j], G, wq, wq2, s0, s1);
-        if (G >= n_groups) {  // K tail: contributes nothing
-          s0 = 0.0f; s1 = 0.0f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) wq[i] = 0;
-        }
-        uint8_t* dst = st + sr * WROW2 + 32 * (sg + 8 * j);
-        *(v4i*)dst = v4i{(int)wq[0], (int)wq[1], (int)wq[2], (int)wq[3]};
-        *(v4i*)(dst + 16) = v4i{(int)wq[4], (int)wq[5], (int)wq[6], (int)wq[7]};
-        float* sdst = (float*)(st + L::W_TILE) + (sg + 8 * j) * SPITCH + sr;
-        sdst[0] = s0;
-        if constexpr (TR::n_scale == 2) sdst[16 * SPITCH] = s1;
-      }
-    };
-    Raw RA[2], RB[2];
-    load2(RA, 0);
-    load2(RB, 1);
-    write2(RA, 0);
-    load2(RA, 2);
-    GGQ_LDS_BARRIER();  // B_0
-    for (int s = 0; s < n_slabs; s += 2) {
-      // after B_s: the stage of slab s+1 held slab s-1, finished by every consumer before B_s
-      if (s + 1 < n_slabs) write2(RB, s + 1);
-      load2(RB, s + 3);
-      GGQ_LDS_BARRIER();  // B_{s+1}
-      if (s + 1 >= n_slabs) break;
-      if (s + 2 < n_slabs) write2(RA, s + 2);
-      load2(RA, s + 4);
-      GGQ_LDS_BARRIER();  // B_{s+2}
-    }
-    GGQ_LDS_BARRIER();  // reduction barrier 1
-    GGQ_LDS_BARRIER();  // reduction barrier 2
-    return;
-  }
-
-  // ================= consumer =================
-  const int tb = wave & 1, kq = wave >> 1;   // 32-token block, 128-element block of every slab
-  v16f acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  v16i magic;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) magic[i] = (int)MAGIC_I;
-  asm volatile("" : "+v"(magic));  // keep the preset accumulator in registers
-  const int r = lane & 31, h = lane >> 5;
-  const int tl = tb * 32 + r;
-
-  // activation streaming: consumer wave cw issues DMA instructions cw, cw+8, ... (< 36) of every slab
-  int64_t dsrc[L::N_DMA];
-#pragma unroll
-  for (int i = 0; i < L::N_DMA; ++i) {
-    const int j = 8 * i + wave;         // DMA instruction index inside the slab
-    const int c = 64 * j + lane;        // 16-byte chunk
-    const int kb = c / (TT * 9);        // which of the slab's four 128-element blocks
-    int within = c - kb * TT * 9;
-    if (within >= n_valid_tok * 9) within = within % 9;  // token outside the batch: any valid bytes
-    dsrc[i] = ((int64_t)min(kb, 3) * batch + t0) * 144 + 16 * within;
-  }
-  const int64_t slab_stride = (int64_t)4 * batch * 144;
-  const bool dma_last = wave < L::N_INSTR - 8 * (L::N_DMA - 1);  // wave-uniform
-  auto dma = [&](int s, uint8_t* st) {
-    const int sc = min(s, n_slabs - 1);  // past the end: harmless re-copy keeps the in-flight count constant
-#pragma unroll
-    for (int i = 0; i < L::N_DMA; ++i) {
-      if (i < L::N_DMA - 1 || dma_last)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(q8 + sc * slab_stride + dsrc[i]),
-            (__attribute__((address_space(3))) void*)(st + 1024 * (8 * i + wave)), 16, 0, 0);
-    }
-  };
-  auto dma_wait = [&]() {  // everything but this wave's most recent slab has landed
-    if (dma_last) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  };
-  static_assert(L::N_DMA == 5, "dma_wait counts assume 5 / 4 DMA instructions per wave and slab");
-
-  auto compute = [&](const uint8_t* wst, const uint8_t* at) {
-    const float* sc = (const float*)(wst + L::W_TILE);
-    const uint8_t* ablk = at + (kq * TT + tl) * 144;   // this token's 128-element block kq of the slab
-    const v4i hd = *(const v4i*)ablk;                  // its four (d, s) words
-    if constexpr (TR::mfma_min) {
-      // Σ_g (-dmin·m)[row,g]·s8[token,g]: K = 2 outer products, group pairs (0,1) and (2,3) of the block
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const float am = sc[16 * SPITCH + (4 * kq + 2 * p + h) * SPITCH + r];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bits_h_f32((uint32_t)hd[2 * p + h] >> 16), acc, 0, 0, 0);
-      }
-    }
-#pragma unroll 2
-    for (int j = 0; j < 4; ++j) {
-      const int g = 4 * kq + j;
-      const uint32_t dsw = (uint32_t)(j == 0 ? hd[0] : j == 1 ? hd[1] : j == 2 ? hd[2] : hd[3]);
-      float bs, bm = 0.0f;
-      if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
-      else bs = as_f32((int)dsw);
-      const float nmbs = -(MAGIC_F * bs);  // exact when bs is an fp16 value (need_sum formats)
-      v16i c0, c1 = magic;
-      if constexpr (TR::half_scales) {
-        const long a0 = *(const long*)(wst + r * WROW2 + 32 * g + 8 * h);
-        const long a1 = *(const long*)(wst + r * WROW2 + 32 * g + 16 + 8 * h);
-        const long b0 = *(const long*)(ablk + 16 + 32 * j + 8 * h);
-        const long b1 = *(const long*)(ablk + 16 + 32 * j + 16 + 8 * h);
-        c0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a0, b0, magic, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1, b1, magic, 0, 0, 0);
-      } else {
-        const v4i a = *(const v4i*)(wst + r * WROW2 + 32 * g + 16 * h);
-        const v4i b = *(const v4i*)(ablk + 16 + 32 * j + 16 * h);
-        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, magic, 0, 0, 0);
-      }
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const v4f sa = *(const v4f*)(sc + g * SPITCH + 8 * qd + 4 * h);
-        v4f sb = {0, 0, 0, 0};
-        if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb = *(const v4f*)(sc + 16 * SPITCH + g * SPITCH + 8 * qd + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * qd + e;
-          const float df0 = as_f32(c0[i]);  // = 12582912 + C exactly
-          if constexpr (TR::fp16_prod) {  // Q4_1/Q5_1, mmq.cuh:527-529 / :840-842
-            const float lo = (float)((_Float16)sa[e] * (_Float16)bs);
-            const float hi = (float)((_Float16)sb[e] * (_Float16)bm);
-            acc[i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
-          } else if constexpr (TR::half_scales) {  // Q6_K (fp32 d8): mmq.cuh:1726-1732
-            const float df1 = as_f32(c1[i]);
-            acc[i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sa[e], acc[i]);
-            acc[i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sb[e], acc[i]);
-          } else if constexpr (TR::need_sum) {  // Q4_0, Q4_K, Q5_K (fp16 d8): float(C)·d8 in one exact fma
-            acc[i] = __builtin_fmaf(__builtin_fmaf(df0, bs, nmbs), sa[e], acc[i]);
-          } else {  // Q5_0 / Q8_0 / Q3_K (fp32 d8): d_w d8 C
-            acc[i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sa[e], acc[i]);
-          }
-        }
-      }
-    }
-  };
-
-  {
-    uint8_t* a0 = lds + L::A_OFF;
-    uint8_t* a1 = a0 + L::A_BYTES;
-    uint8_t* a2 = a1 + L::A_BYTES;
-    dma(0, a0);
-    dma(1, a1);
-    dma_wait();          // slab 0 landed; this wave's DMAs of slab 1 may still be in flight
-    GGQ_LDS_BARRIER();   // B_0
-    for (int s = 0; s < n_slabs; ++s) {
-      dma(s + 2, a2);    // a2 held slab s-1, which every consumer finished before B_s
-      compute(lds + L::W_OFF + (s & 1) * L::WS_STAGE, a0);
-      uint8_t* t = a0; a0 = a1; a1 = a2; a2 = t;
-      dma_wait();        // slab s+1 complete before B_{s+1}
-      GGQ_LDS_BARRIER(); // B_{s+1}
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain before the stage memory is reused
-  }
-
-  // ---- K-block reduction (4 consumers per token block) through LDS ----
-  float* red = (float*)lds;  // [consumer wave][16][64]
-  GGQ_LDS_BARRIER();  // reduction barrier 1: every DMA drained, every wave done with the stages
-  if (kq > 0) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
-  }
-  GGQ_LDS_BARRIER();  // reduction barrier 2
-  if (kq == 0) {
-#pragma unroll
-    for (int s = 1; s < 4; ++s)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += red[((2 * s + tb) * 16 + i) * 64 + lane];
-    const int t = t0 + tl;
-    if (t < batch) {
-      const bool vec_ok = DT != GGQ_F32 && (ldy & 3) == 0 && ((uintptr_t)y & 7) == 0 && n0 + 32 <= n_rows;
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int row = n0 + 8 * qd + 4 * h;
-        if (vec_ok) {
-          uint16_t hv[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (DT == GGQ_F16) hv[e] = __builtin_bit_cast(uint16_t, (_Float16)acc[4 * qd + e]);
-            else hv[e] = Elem<GGQ_BF16>::cvt(acc[4 * qd + e]);
-          }
-          uint2 pk;
-          pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
-          pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
-          *(uint2*)((uint16_t*)y + (int64_t)t * ldy + row) = pk;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (row + e < n_rows) Elem<DT>::st(y, (int64_t)t * ldy + row + e, acc[4 * qd + e]);
-        }
-      }
-    }
-  }
-}
-
-template <int T, int DT>
-static int launch_mmq_ws(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
-                         int64_t ldy, hipStream_t s) {
-  if constexpr (MmqTraits<T>::two_tiles) {
-    return GGQ_ERR_TYPE;  // not reached: Q2_K is routed to the generic kernel
-  } else {
-    using L = MmqWsLds<T>;
-    auto kern = mmq_ws_kernel<T, DT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES) != hipSuccess)
-        return GGQ_ERR_LAUNCH;
-      attr_set = true;
-    }
-    const int64_t n_tok_tiles = (batch + 63) / 64;
-    const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
-    if (n_units > 0x7fffffffLL) return GGQ_ERR_SHAPE;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_units), dim3(768), L::BYTES, s, (const uint8_t*)w,
-                       (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy, (int)n_tok_tiles);
-    GGQ_HIP_CHECK_LAUNCH();
-    return GGQ_OK;
-  }
-}
-
 template <int T, int DT, int TBn>
 static int launch_mmq_cfg(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                           int64_t ldy, hipStream_t s) {
@@ -973,11 +684,6 @@ static int launch_mmq_t(const void* w, const void* q8, void* y, int64_t batch, i
   // shape); 128-token units halve the weight re-staging once there are plenty of units anyway
   const int64_t units128 = ((n + 31) / 32) * ((batch + 127) / 128);
   if (batch <= 64 || units128 < 2048 || !MmqTraits<T>::light) {
-    // opt-in experiment (GGQ_MMQ_WS=1): the warp-specialised 12-wave kernel.  Measured r1: 40.7 us vs
-    // 34.6 us for the generic kernel at Q4_K batch 128 — one workgroup per CU leaves every unit's
-    // prologue/epilogue latency exposed.
-    static const char* e = getenv("GGQ_MMQ_WS");
-    if (e && e[0] == '1' && !MmqTraits<T>::two_tiles) return launch_mmq_ws<T, DT>(w, q8, y, batch, k, n, ldy, s);
     return launch_mmq_cfg<T, DT, 2>(w, q8, y, batch, k, n, ldy, s);
   }
   return launch_mmq_cfg<T, DT, 4>(w, q8, y, batch, k, n, ldy, s);
