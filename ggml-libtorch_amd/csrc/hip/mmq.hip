@@ -1161,7 +1161,9 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
 }  // namespace ggq
 
 extern "C" int ggq_mmq_tiled_supported(int type, int64_t k) {
-  return ggq_type_supported(type) && k > 0 && k % ggq_block_elems(type) == 0;
+  // the streamed kernel addresses a 32-row weight tile with 32-bit byte offsets: rows up to 32 MiB (K of a few
+  // tens of millions); longer rows stay on the reference-layout kernel
+  return ggq_type_supported(type) && k > 0 && k % ggq_block_elems(type) == 0 && ggq_row_bytes(type, k) <= (32 << 20);
 }
 
 extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int type, int dtype,

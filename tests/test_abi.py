@@ -91,3 +91,21 @@ def test_operator_library_loads_and_registers_the_reference_schemas():
         ggml.ggml_dequantize(torch.zeros(18, dtype=torch.uint8), 2, 1, 32)
     with pytest.raises(AssertionError):  # HK/torch-ext/ggml/__init__.py:32-33
         ggml.ggml_mul_mat_vec_a8(torch.zeros(18, dtype=torch.uint8), torch.zeros((2, 32)), 2, 1)
+
+
+def test_scratch_and_tiled_traits():
+    """host logic added with the fragment-major scratch: whole 32-token tiles; which (type, k) the streamed
+    kernel accepts (every supported format, whole blocks, rows within its 32-bit byte offsets)"""
+    L = ggqlib.hip()
+    per_token = (4096 - 4096 % 512 + 512) // 32 * 36
+    for batch, tiles in ((1, 32), (32, 32), (33, 64), (128, 128), (129, 160)):
+        assert L.ggq_mmq_scratch_bytes(batch, 4096) == tiles * per_token
+    for t in WEIGHT_TYPES:
+        qk = BLOCK[t][0]
+        assert L.ggq_mmq_tiled_supported(int(t), 4096) == 1
+        assert L.ggq_mmq_tiled_supported(int(t), 4096 + qk) == 1
+        assert L.ggq_mmq_tiled_supported(int(t), 4096 + qk // 2) == 0
+        assert L.ggq_mmq_tiled_supported(int(t), 0) == 0
+        assert L.ggq_mmq_tiled_supported(int(t), 1 << 28) == 0      # 2^28 elements: rows far beyond 32 MiB
+    assert L.ggq_mmq_tiled_supported(int(GGMLType.Q8_1), 4096) == 0
+    assert L.ggq_mmq_tiled_supported(99, 4096) == 0
