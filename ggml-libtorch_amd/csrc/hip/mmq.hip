@@ -769,19 +769,35 @@ template <int T> struct StreamCfg {
   // formats keep their 18/20/22/24/34-byte blocks back to back (their quant bytes are misaligned anyway).
   static constexpr int TAIL = QK == 256 ? SEG % 16 : 0;  // bytes of the last, partial chunk (0: none)
   static constexpr int PITCH = TAIL ? 16 * CPR : SEG;
-  static constexpr int RPW = 64 / CPR;     // rows per copy window (one 64-lane load)
-  static constexpr int NW = (32 + RPW - 1) / RPW;        // windows per stage
+  // copy windows: one 64-lane load moves up to 64 / CPR rows; the window count is rounded up to a power of two
+  // so that the windows tile the 32 rows exactly (no overrun rows: a stage is 32 x PITCH bytes, which lets two
+  // eight-wave workgroups of 32-token units share a CU's 160 KB)
+  static constexpr int NW0 = (32 + 64 / CPR - 1) / (64 / CPR);
+  static constexpr int NW = NW0 <= 1 ? 1 : NW0 <= 2 ? 2 : NW0 <= 4 ? 4 : NW0 <= 8 ? 8 : NW0 <= 16 ? 16 : 32;
+  static constexpr int RPW = 32 / NW;                    // rows per copy window
   static constexpr int WPI = (NW + IPS - 1) / IPS;       // windows per iteration
-  static constexpr int STAGE = ((NW * RPW * PITCH + 16 + 127) / 128) * 128;
+  static constexpr int STAGE = ((32 * PITCH + 15) / 16) * 16;
   static constexpr int SBUF = 512;                       // [s0 | s1][group of the pair][row] floats
   static constexpr int WAVE = 2 * STAGE + SBUF;
   // three workgroups per CU (168 VGPRs, <= 53 KB LDS) except Q6_K: two result tiles per group and a 210-byte row
   static constexpr int OCC = TR::half_scales ? 2 : 3;
 };
 
+// dynamic LDS of a workgroup with KS K-slices (the K-slice reduction aliases the rings) and how many such
+// workgroups the kernel is compiled to co-reside per CU
+template <int T, int TB, int KS> struct StreamLaunch {
+  static constexpr int RED = (KS - 1) * TB * 16 * 64 * 4;
+  static constexpr int LDS = KS * StreamCfg<T>::WAVE > RED ? KS * StreamCfg<T>::WAVE : RED;
+  // eight slices: 64-token units need ~235 VGPRs (one workgroup per CU); 32-token units stay under 128 and two
+  // workgroups share a CU when their rings fit
+  static constexpr int WG_PER_CU = KS == 4 ? StreamCfg<T>::OCC
+                                           : (TB == 1 && StreamCfg<T>::OCC == 3 && 2 * LDS <= 160 * 1024 ? 2 : 1);
+  static_assert(LDS * WG_PER_CU <= 160 * 1024, "LDS of the resident workgroups");
+};
+
 // KS = K-slices = waves per workgroup: 4 normally; 8 when there are too few units to give every SIMD three waves
 template <int T, int DT, int TB, int KS>
-__global__ void __launch_bounds__(64 * KS, KS == 4 ? StreamCfg<T>::OCC : 1) mmq_stream_kernel(const uint8_t* __restrict__ w,
+__global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU)) mmq_stream_kernel(const uint8_t* __restrict__ w,
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
                                                             int64_t ldy, int n_tok_tiles, int n_units, int per_xcd) {
@@ -1105,9 +1121,7 @@ __global__ void __launch_bounds__(64 * KS, KS == 4 ? StreamCfg<T>::OCC : 1) mmq_
 template <int T, int DT, int TB, int KS>
 static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                                 int64_t ldy, int64_t n_tok_tiles, int64_t n_units, hipStream_t s) {
-  constexpr int LDS = KS * StreamCfg<T>::WAVE;
-  static_assert(LDS >= (KS - 1) * TB * 16 * 64 * 4, "K-slice reduction aliases the rings");
-  static_assert(LDS * (KS == 4 ? StreamCfg<T>::OCC : 1) <= 160 * 1024, "LDS of the resident workgroups");
+  constexpr int LDS = StreamLaunch<T, TB, KS>::LDS;
   auto kern = mmq_stream_kernel<T, DT, TB, KS>;
   if (LDS > 64 * 1024) {
     static bool attr_set = false;
@@ -1130,13 +1144,15 @@ static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t bat
   const int64_t n_tok_tiles = (batch + 32 * TB - 1) / (32 * TB);
   const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
-  // At most one unit per CU (down-projection shapes: 4096 rows x 128 tokens = 256 units): eight K-slices per unit,
-  // so every SIMD still hosts two waves (K = 11008, N = 4096, batch 128: 40.1 -> 32.5 us).  The 235-VGPR
-  // eight-wave workgroup is one per CU, so with more units than CUs it would need a second round (344 units:
-  // 15.6 -> 18.2 us) and the four-slice form stays.
+  // Too few units to give every SIMD three waves: eight K-slices per unit instead of four.
+  //   64-token units (235 VGPRs, one eight-wave workgroup per CU): only with at most one unit per CU (down-projection
+  //   shapes, 4096 rows x 128 tokens = 256 units: 40.1 -> 32.5 us; with 344 units it would need a second round);
+  //   32-token units (<= 128 VGPRs, two workgroups per CU): up to 512 units — the batch <= 32 case of the 11008-row
+  //   shape is otherwise a latency chain of 16 pair-iterations per wave at 1.3 waves per SIMD.
   static const char* e = getenv("GGQ_MMQ_KS");
   const int64_t n_st = (k + StreamCfg<T>::SE - 1) / StreamCfg<T>::SE;
-  const bool ks8 = e ? e[0] == '8' : (n_units <= 256 && n_st >= 16);
+  const bool two_per_cu = StreamLaunch<T, TB, 8>::WG_PER_CU == 2;
+  const bool ks8 = e ? e[0] == '8' : (n_units <= (two_per_cu ? 512 : 256) && n_st >= 16);
   if (ks8) return launch_mmq_stream_ks<T, DT, TB, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
   return launch_mmq_stream_ks<T, DT, TB, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
 }
