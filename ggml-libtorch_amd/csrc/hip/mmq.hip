@@ -786,7 +786,7 @@ template <int T> struct StreamCfg {
 // dynamic LDS of a workgroup with KS K-slices (the K-slice reduction aliases the rings) and how many such
 // workgroups the kernel is compiled to co-reside per CU
 template <int T, int TB, int KS> struct StreamLaunch {
-  static constexpr int RED = (KS - 1) * TB * 16 * 64 * 4;
+  static constexpr int RED = (KS - 1) * TB * 16 * 64 * 4;   // (transposed small-batch variant: fewer registers, same bound)
   static constexpr int LDS = KS * StreamCfg<T>::WAVE > RED ? KS * StreamCfg<T>::WAVE : RED;
   // eight slices: 64-token units need ~235 VGPRs (one workgroup per CU); 32-token units stay under 128 and two
   // workgroups share a CU when their rings fit
@@ -796,7 +796,13 @@ template <int T, int TB, int KS> struct StreamLaunch {
 };
 
 // KS = K-slices = waves per workgroup: 4 normally; 8 when there are too few units to give every SIMD three waves
-template <int T, int DT, int TB, int KS>
+// NR = 0: lane = token, accumulator register = weight row (all 16 registers live).
+// NR = 4 / 8 (batch <= 8 / 16, TB = 1): the MFMA operands are swapped — accumulator register = token, lane = weight
+//   row — so only the NR registers that hold real tokens are scaled: the vector work per 32-group drops from 32 FMAs
+//   to 2·NR.  The weight scale is then a lane scalar (one v_permlane32_swap hands both lane halves the scales of both
+//   groups of the pair: no LDS exchange), the token scales are per register and come from a wave-private LDS line the
+//   token lanes fill (already converted to fp32).
+template <int T, int DT, int TB, int KS, int NR>
 __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU)) mmq_stream_kernel(const uint8_t* __restrict__ w,
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
@@ -804,6 +810,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
   using C = StreamCfg<T>;
   using TR = MmqTraits<T>;
   constexpr int SEG = C::SEG, STAGE = C::STAGE, IPS = C::IPS;
+  static_assert(NR == 0 || (TB == 1 && (NR == 4 || NR == 8)), "transposed variant: one token block, 4 or 8 live registers");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave]{ ring[2][STAGE]; float sb[2][2][32] }
 
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -998,72 +1005,146 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
         }
       }
     }
-    sb[h * 32 + r] = s0;
-    if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb[64 + h * 32 + r] = s1;
-    __builtin_amdgcn_wave_barrier();
-
-    if constexpr (TR::mfma_min) {
-      // min term: Σ (-dmin·m)[row, 2p+h] · s8[token, 2p+h] on the matrix pipe
-#pragma unroll
-      for (int jj = 0; jj < TB; ++jj)
-        acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, bits_h_f32((h ? ds1[jj] : ds0[jj]) >> 16), acc[jj], 0, 0, 0);
-    }
-
-#pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-      v4f sa[4], sbv[4];
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        sa[qd] = *(const v4f*)(sb + gg * 32 + 8 * qd + 4 * h);
-        if constexpr (TR::n_scale == 2 && !TR::mfma_min) sbv[qd] = *(const v4f*)(sb + 64 + gg * 32 + 8 * qd + 4 * h);
+    if constexpr (NR != 0) {
+      // ---- transposed: per-lane weight scales of both groups, per-register token scales through LDS ----
+      float sal[2], sbl[2] = {0.0f, 0.0f};
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s0), false, false);
+        sal[0] = as_f32((int)sw[0]); sal[1] = as_f32((int)sw[1]);   // scales of groups 2p, 2p+1 of row r, in both halves
+        if constexpr (TR::n_scale == 2 && !TR::mfma_min) {
+          const auto sw1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, s1), false, false);
+          sbl[0] = as_f32((int)sw1[0]); sbl[1] = as_f32((int)sw1[1]);
+        }
       }
-      v4i alo = a[gg], ahi = a[gg];
-      if constexpr (TR::half_scales) {   // Q6_K: separate sums over k < 16 and k >= 16 — zero the other half's lanes
+      // token lanes (h = 0) publish {bs, aux} of both groups: aux = -12582912·bs (fp16 d8), s8 (fp16 products), unused
+      float bsl[2], auxl[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { alo[i] = h == 0 ? a[gg][i] : 0; ahi[i] = h == 1 ? a[gg][i] : 0; }
+      for (int gg = 0; gg < 2; ++gg) {
+        const uint32_t dsw = gg ? ds1[0] : ds0[0];
+        if constexpr (TR::need_sum) {
+          bsl[gg] = bits_h_f32(dsw & 0xFFFF);
+          auxl[gg] = TR::fp16_prod ? bits_h_f32(dsw >> 16) : -(MAGIC_F * bsl[gg]);
+        } else {
+          bsl[gg] = as_f32((int)dsw); auxl[gg] = 0.0f;
+        }
       }
+      if (h == 0) *(v4f*)(sb + 4 * r) = v4f{bsl[0], auxl[0], bsl[1], auxl[1]};
+      __builtin_amdgcn_wave_barrier();
+
+      if constexpr (TR::mfma_min) {
+        // min term, operands swapped: rows = tokens (s8 of token lane & 31, group 2p+h), columns = weight rows
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bits_h_f32((h ? ds1[0] : ds0[0]) >> 16), s1, acc[0], 0, 0, 0);
+      }
+      v4f tk[NR];   // {bs0, aux0, bs1, aux1} of the token of accumulator register i: token 8 (i >> 2) + 4 h + (i & 3)
 #pragma unroll
-      for (int jj = 0; jj < TB; ++jj) {
-        const uint32_t dsw = gg ? ds1[jj] : ds0[jj];
-        float bs, bm = 0.0f;
-        if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
-        else bs = as_f32((int)dsw);
-        const float nmbs = -(MAGIC_F * bs);   // exact when bs is an fp16 value (need_sum formats)
+      for (int i = 0; i < NR; ++i) tk[i] = *(const v4f*)(sb + 4 * (8 * (i >> 2) + 4 * h + (i & 3)));
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        v4i alo = a[gg], ahi = a[gg];
+        if constexpr (TR::half_scales) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { alo[i] = h == 0 ? a[gg][i] : 0; ahi[i] = h == 1 ? a[gg][i] : 0; }
+        }
         v16i c0, c1 = magic;
         if constexpr (TR::half_scales) {
-          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B[jj][gg], magic, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B[jj][gg], magic, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], alo, magic, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], ahi, magic, 0, 0, 0);
         } else {
-          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[gg], B[jj][gg], magic, 0, 0, 0);
-          if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[gg], B[jj][gg], magic, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a[gg], magic, 0, 0, 0);
+          if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a2[gg], magic, 0, 0, 0);
         }
-        B[jj][gg] = *(gptr_v4i)(abase[jj] + 1024 * gg + lane16);   // refill in place: a full iteration of lead
+        B[0][gg] = *(gptr_v4i)(abase[0] + 1024 * gg + lane16);
+        const float sae = sal[gg], sbe = sbl[gg];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = 4 * qd + e;
-            const float df0 = as_f32(c0[i]);   // = 12582912 + C exactly
-            const float sae = sa[qd][e];
-            // explicit fma + -ffp-contract=off: every accumulator register sees the same instruction
-            // sequence, so a row's result does not depend on its position in the tile
-            if constexpr (TR::fp16_prod) {   // Q4_1/Q5_1, mmq.cuh:527-529 / :840-842
-              const float lo = (float)((_Float16)sae * (_Float16)bs);
-              const float hi = (float)((_Float16)sbv[qd][e] * (_Float16)bm);
-              acc[jj][i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
-            } else if constexpr (TR::two_tiles) {   // Q2_K: d8 (dall·Σsc q q8 − dmin·Σ m q8), mmq.cuh:47
-              const float df1 = as_f32(c1[i]);
-              acc[jj][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, df0 - MAGIC_F, -(sbv[qd][e] * (df1 - MAGIC_F))), acc[jj][i]);
-            } else if constexpr (TR::half_scales) {   // Q6_K (fp32 d8): mmq.cuh:1726-1732
-              const float df1 = as_f32(c1[i]);
-              acc[jj][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[jj][i]);
-              acc[jj][i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sbv[qd][e], acc[jj][i]);
-            } else if constexpr (TR::need_sum) {   // Q4_0, Q4_K, Q5_K (fp16 d8): float(C)·d8 in one exact fma
-              acc[jj][i] = __builtin_fmaf(__builtin_fmaf(df0, bs, nmbs), sae, acc[jj][i]);
-            } else {   // Q5_0 / Q8_0 / Q3_K (fp32 d8): d_w d8 C
-              acc[jj][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[jj][i]);
-            }
+        for (int i = 0; i < NR; ++i) {
+          const float df0 = as_f32(c0[i]);
+          const float bs = gg ? tk[i][2] : tk[i][0], aux = gg ? tk[i][3] : tk[i][1];
+          if constexpr (TR::fp16_prod) {
+            const float lo = (float)((_Float16)sae * (_Float16)bs);
+            const float hi = (float)((_Float16)sbe * (_Float16)aux);
+            acc[0][i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
+          } else if constexpr (TR::two_tiles) {
+            const float df1 = as_f32(c1[i]);
+            acc[0][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, df0 - MAGIC_F, -(sbe * (df1 - MAGIC_F))), acc[0][i]);
+          } else if constexpr (TR::half_scales) {
+            const float df1 = as_f32(c1[i]);
+            acc[0][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[0][i]);
+            acc[0][i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sbe, acc[0][i]);
+          } else if constexpr (TR::need_sum) {
+            acc[0][i] = __builtin_fmaf(__builtin_fmaf(df0, bs, aux), sae, acc[0][i]);
+          } else {
+            acc[0][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[0][i]);
           }
+        }
+      }
+    } else {
+      sb[h * 32 + r] = s0;
+      if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb[64 + h * 32 + r] = s1;
+      __builtin_amdgcn_wave_barrier();
+
+      if constexpr (TR::mfma_min) {
+        // min term: Σ (-dmin·m)[row, 2p+h] · s8[token, 2p+h] on the matrix pipe
+  #pragma unroll
+        for (int jj = 0; jj < TB; ++jj)
+          acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, bits_h_f32((h ? ds1[jj] : ds0[jj]) >> 16), acc[jj], 0, 0, 0);
+      }
+
+  #pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        v4f sa[4], sbv[4];
+  #pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          sa[qd] = *(const v4f*)(sb + gg * 32 + 8 * qd + 4 * h);
+          if constexpr (TR::n_scale == 2 && !TR::mfma_min) sbv[qd] = *(const v4f*)(sb + 64 + gg * 32 + 8 * qd + 4 * h);
+        }
+        v4i alo = a[gg], ahi = a[gg];
+        if constexpr (TR::half_scales) {   // Q6_K: separate sums over k < 16 and k >= 16 — zero the other half's lanes
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) { alo[i] = h == 0 ? a[gg][i] : 0; ahi[i] = h == 1 ? a[gg][i] : 0; }
+        }
+  #pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+          const uint32_t dsw = gg ? ds1[jj] : ds0[jj];
+          float bs, bm = 0.0f;
+          if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
+          else bs = as_f32((int)dsw);
+          const float nmbs = -(MAGIC_F * bs);   // exact when bs is an fp16 value (need_sum formats)
+          v16i c0, c1 = magic;
+          if constexpr (TR::half_scales) {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B[jj][gg], magic, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B[jj][gg], magic, 0, 0, 0);
+          } else {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[gg], B[jj][gg], magic, 0, 0, 0);
+            if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[gg], B[jj][gg], magic, 0, 0, 0);
+          }
+          B[jj][gg] = *(gptr_v4i)(abase[jj] + 1024 * gg + lane16);   // refill in place: a full iteration of lead
+  #pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = 4 * qd + e;
+              const float df0 = as_f32(c0[i]);   // = 12582912 + C exactly
+              const float sae = sa[qd][e];
+              // explicit fma + -ffp-contract=off: every accumulator register sees the same instruction
+              // sequence, so a row's result does not depend on its position in the tile
+              if constexpr (TR::fp16_prod) {   // Q4_1/Q5_1, mmq.cuh:527-529 / :840-842
+                const float lo = (float)((_Float16)sae * (_Float16)bs);
+                const float hi = (float)((_Float16)sbv[qd][e] * (_Float16)bm);
+                acc[jj][i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
+              } else if constexpr (TR::two_tiles) {   // Q2_K: d8 (dall·Σsc q q8 − dmin·Σ m q8), mmq.cuh:47
+                const float df1 = as_f32(c1[i]);
+                acc[jj][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, df0 - MAGIC_F, -(sbv[qd][e] * (df1 - MAGIC_F))), acc[jj][i]);
+              } else if constexpr (TR::half_scales) {   // Q6_K (fp32 d8): mmq.cuh:1726-1732
+                const float df1 = as_f32(c1[i]);
+                acc[jj][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[jj][i]);
+                acc[jj][i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sbv[qd][e], acc[jj][i]);
+              } else if constexpr (TR::need_sum) {   // Q4_0, Q4_K, Q5_K (fp16 d8): float(C)·d8 in one exact fma
+                acc[jj][i] = __builtin_fmaf(__builtin_fmaf(df0, bs, nmbs), sae, acc[jj][i]);
+              } else {   // Q5_0 / Q8_0 / Q3_K (fp32 d8): d_w d8 C
+                acc[jj][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[jj][i]);
+              }
+            }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1073,11 +1154,12 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
   // ---- K-slice reduction (the rings are dead once every wave has passed its last ds_read) ----
   __syncthreads();
   float* red = (float*)lds;   // [KS - 1][TB][16][64]
+  constexpr int NLIVE = NR ? NR : 16;
   if (ks > 0) {
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) red[(((ks - 1) * TB + jj) * 16 + i) * 64 + lane] = acc[jj][i];
+      for (int i = 0; i < NLIVE; ++i) red[(((ks - 1) * TB + jj) * 16 + i) * 64 + lane] = acc[jj][i];
   }
   __syncthreads();
   GGQ_STAMP(3);
@@ -1087,8 +1169,18 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[jj][i] += red[((s * TB + jj) * 16 + i) * 64 + lane];
+      for (int i = 0; i < NLIVE; ++i) acc[jj][i] += red[((s * TB + jj) * 16 + i) * 64 + lane];
 
+  if constexpr (NR != 0) {
+    // register i = token t0 + 8 (i >> 2) + 4 h + (i & 3), lane & 31 = weight row: 32 consecutive rows per store
+    if (n0 + r < n_rows) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int t = t0 + 8 * (i >> 2) + 4 * h + (i & 3);
+        if (t < batch) Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, acc[0][i]);
+      }
+    }
+  } else {
   const bool vec_ok = DT != GGQ_F32 && (ldy & 3) == 0 && ((uintptr_t)y & 7) == 0 && n0 + 32 <= n_rows;
 #pragma unroll
   for (int jj = 0; jj < TB; ++jj) {
@@ -1115,14 +1207,15 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
       }
     }
   }
+  }
   GGQ_STAMP(4);
 }
 
-template <int T, int DT, int TB, int KS>
+template <int T, int DT, int TB, int KS, int NR>
 static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                                 int64_t ldy, int64_t n_tok_tiles, int64_t n_units, hipStream_t s) {
   constexpr int LDS = StreamLaunch<T, TB, KS>::LDS;
-  auto kern = mmq_stream_kernel<T, DT, TB, KS>;
+  auto kern = mmq_stream_kernel<T, DT, TB, KS, NR>;
   if (LDS > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1153,8 +1246,18 @@ static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t bat
   const int64_t n_st = (k + StreamCfg<T>::SE - 1) / StreamCfg<T>::SE;
   const bool two_per_cu = StreamLaunch<T, TB, 8>::WG_PER_CU == 2;
   const bool ks8 = e ? e[0] == '8' : (n_units <= (two_per_cu ? 512 : 256) && n_st >= 16);
-  if (ks8) return launch_mmq_stream_ks<T, DT, TB, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
-  return launch_mmq_stream_ks<T, DT, TB, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+  if constexpr (TB == 1) {   // batch <= 16: transposed variant, only the registers that hold tokens are scaled
+    static const char* et = getenv("GGQ_MMQ_TRANS");
+    const bool trans = et ? et[0] == '1' : true;
+    if (trans && batch <= 8)
+      return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s)
+                 : launch_mmq_stream_ks<T, DT, 1, 4, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+    if (trans && batch <= 16)
+      return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s)
+                 : launch_mmq_stream_ks<T, DT, 1, 4, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+  }
+  if (ks8) return launch_mmq_stream_ks<T, DT, TB, 8, 0>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+  return launch_mmq_stream_ks<T, DT, TB, 4, 0>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
 }
 }  // namespace ggq
 
