@@ -42,7 +42,7 @@ extern "C" int ggq_debug_read_stamps(void* dst, long long n) {
 }
 #define GGQ_STAMP(i)                                                                             \
   do {                                                                                           \
-    if (lane == 0 && blockIdx.x < 2048) g_stamps[(blockIdx.x * 4 + ks) * 8 + (i)] = wall_clock64(); \
+    if (lane == 0 && blockIdx.x < 1024) g_stamps[(blockIdx.x * 8 + ks) * 8 + (i)] = wall_clock64(); \
   } while (0)
 #else
 #define GGQ_STAMP(i) do {} while (0)
@@ -777,7 +777,7 @@ template <int T> struct StreamCfg {
   static constexpr int RPW = 32 / NW;                    // rows per copy window
   static constexpr int WPI = (NW + IPS - 1) / IPS;       // windows per iteration
   static constexpr int STAGE = ((32 * PITCH + 15) / 16) * 16;
-  static constexpr int SBUF = 512;                       // [s0 | s1][group of the pair][row] floats
+  static constexpr int SBUF = 1024;                      // two copies (pair parity) of [s0 | s1][group of the pair][row] floats
   static constexpr int WAVE = 2 * STAGE + SBUF;
   // three workgroups per CU (168 VGPRs, <= 53 KB LDS) except Q6_K: two result tiles per group and a 210-byte row
   static constexpr int OCC = TR::half_scales ? 2 : 3;
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
   const int n_st = (k + C::SE - 1) / C::SE;
   const int st_begin = (int)((int64_t)ks * n_st / KS), st_end = (int)((int64_t)(ks + 1) * n_st / KS);
   uint8_t* ring = lds + ks * C::WAVE;
-  float* sb = (float*)(ring + 2 * STAGE);
+  float* sb0 = (float*)(ring + 2 * STAGE);   // scale exchange line, double-buffered by pair parity
   const int n_tt32 = (batch + 31) / 32;
   const uint32_t lane16 = lane * 16;
   const uint8_t* wtile = w + (int64_t)n0 * row_bytes;
@@ -919,6 +919,8 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
   GGQ_STAMP(1);
 #endif
 
+  constexpr int UNROLL = TB == 1 ? 2 : 1;   // 32-token units have registers to spare: overlap two pair-iterations
+#pragma unroll UNROLL
   for (int p = p_begin; p < p_end; ++p) {
     const int st = p / IPS, q = p % IPS;
     // abase[] points at pair p; step to the next pair (the last iteration re-reads its own pair)
@@ -926,6 +928,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
     const int64_t step = !more ? 0 : (p & 1) ? kb_stride - 2048 : 2048;
     const int ds_off = (((p & 1) != 0) == more) ? 4096 : 2304;   // next pair even -> +4096, odd -> +2304
     const uint8_t* stage = ring + (st & 1) * STAGE + r * C::PITCH;
+    float* sb = sb0 + (p & 1) * 128;
 
     // ---- raw weight bytes of this lane from the ring (before the ring is written below) ----
     Raw R;
@@ -1016,14 +1019,14 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
           sbl[0] = as_f32((int)sw1[0]); sbl[1] = as_f32((int)sw1[1]);
         }
       }
-      // token lanes (h = 0) publish {bs, aux} of both groups: aux = -12582912·bs (fp16 d8), s8 (fp16 products), unused
+      // token lanes (h = 0) publish {bs, aux} of both groups: aux = s8 for the fp16-product formats, else unused
       float bsl[2], auxl[2];
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) {
         const uint32_t dsw = gg ? ds1[0] : ds0[0];
         if constexpr (TR::need_sum) {
           bsl[gg] = bits_h_f32(dsw & 0xFFFF);
-          auxl[gg] = TR::fp16_prod ? bits_h_f32(dsw >> 16) : -(MAGIC_F * bsl[gg]);
+          auxl[gg] = TR::fp16_prod ? bits_h_f32(dsw >> 16) : 0.0f;
         } else {
           bsl[gg] = as_f32((int)dsw); auxl[gg] = 0.0f;
         }
@@ -1045,35 +1048,36 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
 #pragma unroll
           for (int i = 0; i < 4; ++i) { alo[i] = h == 0 ? a[gg][i] : 0; ahi[i] = h == 1 ? a[gg][i] : 0; }
         }
-        v16i c0, c1 = magic;
+        // (few live registers: a zero accumulator input + v_cvt_f32_i32 on the live registers is cheaper than
+        //  keeping the 16-register 0x4B400000 constant alive; (float)C·d8 rounds exactly like the preset trick)
+        const v16i zero = {};
+        v16i c0, c1 = zero;
         if constexpr (TR::half_scales) {
-          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], alo, magic, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], ahi, magic, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], alo, zero, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], ahi, zero, 0, 0, 0);
         } else {
-          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a[gg], magic, 0, 0, 0);
-          if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a2[gg], magic, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a[gg], zero, 0, 0, 0);
+          if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a2[gg], zero, 0, 0, 0);
         }
         B[0][gg] = *(gptr_v4i)(abase[0] + 1024 * gg + lane16);
         const float sae = sal[gg], sbe = sbl[gg];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          const float df0 = as_f32(c0[i]);
+          const float cf0 = (float)c0[i];
           const float bs = gg ? tk[i][2] : tk[i][0], aux = gg ? tk[i][3] : tk[i][1];
           if constexpr (TR::fp16_prod) {
             const float lo = (float)((_Float16)sae * (_Float16)bs);
             const float hi = (float)((_Float16)sbe * (_Float16)aux);
-            acc[0][i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
+            acc[0][i] += __builtin_fmaf(lo, cf0, hi);
           } else if constexpr (TR::two_tiles) {
-            const float df1 = as_f32(c1[i]);
-            acc[0][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, df0 - MAGIC_F, -(sbe * (df1 - MAGIC_F))), acc[0][i]);
+            const float cf1 = (float)c1[i];
+            acc[0][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, cf0, -(sbe * cf1)), acc[0][i]);
           } else if constexpr (TR::half_scales) {
-            const float df1 = as_f32(c1[i]);
-            acc[0][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[0][i]);
-            acc[0][i] = __builtin_fmaf((df1 - MAGIC_F) * bs, sbe, acc[0][i]);
-          } else if constexpr (TR::need_sum) {
-            acc[0][i] = __builtin_fmaf(__builtin_fmaf(df0, bs, aux), sae, acc[0][i]);
+            const float cf1 = (float)c1[i];
+            acc[0][i] = __builtin_fmaf(cf0 * bs, sae, acc[0][i]);
+            acc[0][i] = __builtin_fmaf(cf1 * bs, sbe, acc[0][i]);
           } else {
-            acc[0][i] = __builtin_fmaf((df0 - MAGIC_F) * bs, sae, acc[0][i]);
+            acc[0][i] = __builtin_fmaf(cf0 * bs, sae, acc[0][i]);
           }
         }
       }
@@ -1147,7 +1151,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    // (no barrier here: the scale line is double-buffered by pair parity, so the next iteration may start early)
   }
 
   GGQ_STAMP(2);
