@@ -793,6 +793,7 @@ template <int T, int TB, int KS> struct StreamLaunch {
   static constexpr int WG_PER_CU = KS == 4 ? StreamCfg<T>::OCC
                                            : (TB == 1 && StreamCfg<T>::OCC == 3 && 2 * LDS <= 160 * 1024 ? 2 : 1);
   static_assert(LDS * WG_PER_CU <= 160 * 1024, "LDS of the resident workgroups");
+  // (the second __launch_bounds__ argument of hipcc is waves per SIMD: WG_PER_CU * KS / 4)
 };
 
 // KS = K-slices = waves per workgroup: 4 normally; 8 when there are too few units to give every SIMD three waves
@@ -803,7 +804,7 @@ template <int T, int TB, int KS> struct StreamLaunch {
 //   groups of the pair: no LDS exchange), the token scales are per register and come from a wave-private LDS line the
 //   token lanes fill (already converted to fp32).
 template <int T, int DT, int TB, int KS, int NR>
-__global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU)) mmq_stream_kernel(const uint8_t* __restrict__ w,
+__global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU * KS / 4)) mmq_stream_kernel(const uint8_t* __restrict__ w,
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
                                                             int64_t ldy, int n_tok_tiles, int n_units, int per_xcd) {
@@ -919,8 +920,6 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU))
   GGQ_STAMP(1);
 #endif
 
-  constexpr int UNROLL = TB == 1 ? 2 : 1;   // 32-token units have registers to spare: overlap two pair-iterations
-#pragma unroll UNROLL
   for (int p = p_begin; p < p_end; ++p) {
     const int st = p / IPS, q = p % IPS;
     // abase[] points at pair p; step to the next pair (the last iteration re-reads its own pair)
