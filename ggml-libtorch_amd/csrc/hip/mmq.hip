@@ -773,10 +773,14 @@ template <int T> struct StreamCfg {
   // so that the windows tile the 32 rows exactly (no overrun rows: a stage is 32 x PITCH bytes, which lets two
   // eight-wave workgroups of 32-token units share a CU's 160 KB)
   static constexpr int NW0 = (32 + 64 / CPR - 1) / (64 / CPR);
-  static constexpr int NW = NW0 <= 1 ? 1 : NW0 <= 2 ? 2 : NW0 <= 4 ? 4 : NW0 <= 8 ? 8 : NW0 <= 16 ? 16 : 32;
-  static constexpr int RPW = 32 / NW;                    // rows per copy window
-  static constexpr int WPI = (NW + IPS - 1) / IPS;       // windows per iteration
-  static constexpr int STAGE = ((32 * PITCH + 15) / 16) * 16;
+  static constexpr int NWP = NW0 <= 1 ? 1 : NW0 <= 2 ? 2 : NW0 <= 4 ? 4 : NW0 <= 8 ? 8 : NW0 <= 16 ? 16 : 32;
+  // ... unless that costs an extra load per iteration (Q8_0: 5 windows over 2 iterations = 3 per iteration, 8
+  // would be 4: measured 41 -> 47 us); then the windows keep their natural size and the stage holds the overrun rows
+  static constexpr bool TILING = (NWP + IPS - 1) / IPS == (NW0 + IPS - 1) / IPS;
+  static constexpr int NW = TILING ? NWP : NW0;
+  static constexpr int RPW = TILING ? 32 / NW : 64 / CPR;   // rows per copy window
+  static constexpr int WPI = (NW + IPS - 1) / IPS;          // windows per iteration
+  static constexpr int STAGE = (((TILING ? 32 : NW * RPW) * PITCH + (TILING ? 0 : 16) + 15) / 16) * 16;
   static constexpr int SBUF = 1024;                      // two copies (pair parity) of [s0 | s1][group of the pair][row] floats
   static constexpr int WAVE = 2 * STAGE + SBUF;
   // three workgroups per CU (168 VGPRs, <= 53 KB LDS) except Q6_K: two result tiles per group and a 210-byte row
