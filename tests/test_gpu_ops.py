@@ -134,3 +134,31 @@ def test_op_errors(ops):
     with pytest.raises(RuntimeError):
         ops.ggml_mul_mat_a8(w[:, :100].contiguous(), x, 2, 4)  # wrong byte count
     assert ops.ggml_mul_mat_a8(w, x[:0], 2, 4).shape == (0, 4)
+
+
+@pytest.mark.parametrize("quant_type", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q6_K, GGMLType.Q4_0], ids=lambda t: t.name)
+@pytest.mark.parametrize("num_tokens", [7, 40, 128])
+@torch.inference_mode()
+def test_shared_activation_quantisation(ops, quant_type, num_tokens):
+    """ggq.linear: quantise X once, multiply by gate and up — bit-identical to two ggml_mul_mat_a8 calls whenever
+    that op takes the streamed kernel (same two kernels, the first hoisted), within the op's tolerance otherwise"""
+    from ggq import linear
+    hidden, rows = 1024, 352
+    torch.manual_seed(1)
+    x = torch.randn((num_tokens, hidden), dtype=torch.half, device="cuda")
+    wg = torch.tensor(synth.random_weight(quant_type, rows, hidden, seed=1), device="cuda")
+    wu = torch.tensor(synth.random_weight(quant_type, rows, hidden, seed=2), device="cuda")
+    yg, yu = linear.gate_up(x, wg, wu, quant_type, rows)
+    rg = ops.ggml_mul_mat_a8(wg, x, quant_type, rows)
+    ru = ops.ggml_mul_mat_a8(wu, x, quant_type, rows)
+    streamed_from = {GGMLType.Q8_0: 65, GGMLType.Q6_K: 33}.get(quant_type, 5)
+    if num_tokens >= streamed_from:
+        assert torch.equal(yg, rg) and torch.equal(yu, ru)
+    else:
+        torch.testing.assert_close(yg, rg, atol=2e-2, rtol=2e-3)
+        torch.testing.assert_close(yu, ru, atol=2e-2, rtol=2e-3)
+    from ggq.formats import NEED_SUM
+    mine = quant_type in NEED_SUM
+    other = GGMLType.Q8_0 if mine else GGMLType.Q4_K   # a format of the other scratch flavour
+    with pytest.raises(ValueError):
+        linear.QuantizedActivations(x, mine).matmul(wg, other, rows)
