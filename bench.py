@@ -341,6 +341,13 @@ def secondary_configs(L, dev, w_q4k, x128, scratch, args):
     res["quantize_mmq_q8_1_batch128"] = {"us": round(us, 3)}
     us, _ = time_launches(lambda: L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 200, use_graph=g)
     res["quantize_q8_1_tiled_batch128"] = {"us": round(us, 3)}
+    # FFN gate + up on one activation quantisation (ggq.linear): quantise once, two streamed matmuls
+    def gate_up():
+        L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
+        L.ggq_mul_mat_q_pretiled(vp(w_q4k), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+        L.ggq_mul_mat_q_pretiled(vp(ws[Q5_K]), vp(scratch), vp(y128), Q5_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+    us, _ = time_launches(gate_up, 100, use_graph=g)
+    res["gate_up_Q4_K_Q5_K_batch128_shared_quantisation"] = {"us": round(us, 3), "note": "two separate ggml_mul_mat_a8 calls: mmq_Q4_K + mmq_Q5_K step times"}
     # the reference-layout kernel (other formats' path) on the headline shape, for comparison
     L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
     us, _ = time_launches(lambda: L.ggq_mul_mat_q_prequant(vp(w_q4k), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream()), 100, use_graph=g)
