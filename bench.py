@@ -341,6 +341,19 @@ def secondary_configs(L, dev, w_q4k, x128, scratch, args):
     res["quantize_mmq_q8_1_batch128"] = {"us": round(us, 3)}
     us, _ = time_launches(lambda: L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 200, use_graph=g)
     res["quantize_q8_1_tiled_batch128"] = {"us": round(us, 3)}
+    # BASELINE configs[4]: the per-rank shard of Q4_K 8192 x 28672 over 8 GPUs = 3584 rows x K 8192, batch 1 / 8 / 128
+    K5, N5 = 8192, 3584
+    w5 = torch.from_numpy(synth.random_weight(Q4_K, N5, K5, seed=5)).to(dev)
+    x5 = torch.randn((BATCH, K5), generator=torch.Generator().manual_seed(5)).half().to(dev)
+    y5 = torch.empty((BATCH, N5), dtype=torch.float16, device=dev)
+    sc5 = torch.empty(int(L.ggq_mmq_scratch_bytes(BATCH, K5)), dtype=torch.uint8, device=dev)
+    for b in (8, BATCH):
+        xb = x5[:b].contiguous()
+        us, _ = time_launches(lambda: L.ggq_mul_mat_q(vp(w5), vp(xb), vp(y5), Q4_K, 1, b, K5, N5, vp(sc5), cur_stream()), 100, use_graph=g)
+        rec(f"mmq_Q4_K_shard_3584x8192_batch{b}", us, algo_bytes_matmul(Q4_K, N5, K5, b), 2.0 * b * N5 * K5)
+    x51 = x5[:1].contiguous()
+    us, _ = time_launches(lambda: L.ggq_mul_mat_vec_q(vp(w5), vp(x51), vp(y5), Q4_K, 1, K5, N5, vp(sc5), cur_stream()), 200, use_graph=g)
+    rec("mmvq_Q4_K_shard_3584x8192_batch1", us, algo_bytes_matmul(Q4_K, N5, K5, 1), 2.0 * N5 * K5)
     # FFN gate + up on one activation quantisation (ggq.linear): quantise once, two streamed matmuls
     def gate_up():
         L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())

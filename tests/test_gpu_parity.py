@@ -269,6 +269,25 @@ def test_mmq_transposed_shape_rows_sample(oracle, t):
         util.assert_fp_accumulate(y[:, torch.from_numpy(rows).cuda()], ref, yabs, torch.float16, f"mmq transposed {t.name} b={batch}")
 
 
+@pytest.mark.parametrize("batch", [1, 8, 128])
+def test_config5_shard_shape(oracle, batch):
+    """BASELINE configs[4]: Q4_K 8192 x 28672 sharded over 8 GPUs = 3584 rows x K 8192 per rank, batch 1 / 8 / 128
+    (batch 1 through the GEMV op): oracle on a sample of rows; exercises the eight-K-slice launches (112 / 224 units)."""
+    t, n_rows, k = GGMLType.Q4_K, 3584, 8192
+    w = synth.random_weight(t, n_rows, k, seed=41)
+    x = _x((batch, k), torch.float16, seed=42)
+    rows = np.r_[0:20, 1790:1810, n_rows - 20:n_rows]
+    sel = torch.from_numpy(rows).cuda()
+    if batch == 1:
+        y = util.gpu_mmvq(w, x, t, n_rows)
+        ref, yabs = oracle.mul_mat_vec_q(w[rows], x.float().cpu().numpy(), t, len(rows))
+        util.assert_fp_accumulate(y[:, sel], ref.reshape(1, -1), yabs.reshape(1, -1), torch.float16, "config5 mmvq")
+    else:
+        y = util.gpu_mmq(w, x, t, n_rows)
+        ref, yabs = oracle.mul_mat_q(w[rows], x.float().cpu().numpy(), t, len(rows))
+        util.assert_fp_accumulate(y[:, sel], ref, yabs, torch.float16, f"config5 mmq b={batch}")
+
+
 @pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q4_K], ids=lambda t: t.name)
 def test_mmvq_full_size(oracle, t):
     """BASELINE config 3 shape: batch 1, K=4096, N=11008."""
