@@ -18,9 +18,24 @@
 //   * no LDS: nothing is reused across lanes except the block header.
 #include "ggq_common.h"
 
+#ifndef GGQ_DEQUANT_CH
+#define GGQ_DEQUANT_CH(T) 1   // chunks per thread; 2 was measured slower for every format but Q3_K (the two
+                               // 16-byte stores of a lane are 32 bytes apart: Q4_K 73 % -> 62 % of the roof)
+#endif
+
 namespace ggq {
 
 __device__ __forceinline__ _Float16 i2h(int v) { return (_Float16)v; }  // __int2half_rn
+
+// Packed path of the K-quant decoders: the integer field extraction runs on four bytes per dword, the bytes
+// (0..255, exact in fp16) become half2 pairs via v_cvt_f32_ubyteN + v_cvt_pkrtz_f16_f32, and every __hmul / __hsub
+// of the reference is a v_pk_*_f16 on two elements — the same IEEE operation per element, half the vector
+// instructions (these formats were VALU-bound at 55-62 % of the HBM roof with the scalar sequence).
+__device__ __forceinline__ h2 u8pair_to_h2(uint32_t p, int pair) {   // bytes 2·pair, 2·pair+1 of p
+  const float a = (float)((p >> (16 * pair)) & 0xFF), b = (float)((p >> (16 * pair + 8)) & 0xFF);
+  return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ void st_h2(_Float16* y, int i, h2 v) { y[i] = v[0]; y[i + 1] = v[1]; }
 
 // ---- per-format decode of the 8-element chunk `sub` of one block -----------
 template <int T> struct Decode;
@@ -117,11 +132,13 @@ template <> struct Decode<GGQ_TYPE_Q3_K> {
     const u32x2_a2 q = ld_u32x2(b + off::Q3_K_QS + 32 * n + l0);
     const u32x2_a2 hm = ld_u32x2(b + off::Q3_K_HM + l0);
     const int hbit = 4 * n + j;
+    const h2 dl2 = {dl, dl}, four = {(_Float16)4.0f, (_Float16)4.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int v = (q.v[i >> 2] >> (8 * (i & 3) + 2 * j)) & 3;
-      const int hset = (hm.v[i >> 2] >> (8 * (i & 3) + hbit)) & 1;
-      y[i] = dl * i2h(v - (hset ? 0 : 4));  // dequantize.cuh:151
+    for (int w = 0; w < 2; ++w) {
+      // bytes: q2 + 4·h in 0..7; (q2 - (h ? 0 : 4)) = that minus 4 — exact either way (dequantize.cuh:151)
+      const uint32_t v4 = ((q.v[w] >> (2 * j)) & 0x03030303u) + (((hm.v[w] >> hbit) & 0x01010101u) << 2);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, dl2 * (u8pair_to_h2(v4, pr) - four));
     }
   }
 };
@@ -135,10 +152,12 @@ template <> struct Decode<GGQ_TYPE_Q4_K> {
     k4_scale_min(hd.v[1], hd.v[2], hd.v[3], sub >> 2, sc, mn);
     const _Float16 d1 = dall * i2h(sc), m1 = dmin * i2h(mn);
     const u32x2_a2 q = ld_u32x2(b + off::Q4_K_QS + 32 * il + l0);
+    const h2 d2 = {d1, d1}, m2 = {m1, m1};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int v = (q.v[i >> 2] >> (8 * (i & 3) + 4 * hsel)) & 0xF;
-      y[i] = d1 * i2h(v) - m1;  // dequantize.cuh:190-191
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = (q.v[w] >> (4 * hsel)) & 0x0F0F0F0Fu;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, d2 * u8pair_to_h2(v4, pr) - m2);  // dequantize.cuh:190-191
     }
   }
 };
@@ -153,11 +172,12 @@ template <> struct Decode<GGQ_TYPE_Q5_K> {
     const u32x2_a2 q = ld_u32x2(b + off::Q5_K_QS + 32 * il + l0);
     const u32x2_a2 qh = ld_u32x2(b + off::Q5_K_QH + l0);
     const int hbit = sub >> 2;  // bit 2il + h of qh[l]
+    const h2 d2 = {d1, d1}, m2 = {m1, m1};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int v = ((q.v[i >> 2] >> (8 * (i & 3) + 4 * hsel)) & 0xF) +
-                    (((qh.v[i >> 2] >> (8 * (i & 3) + hbit)) & 1) << 4);
-      y[i] = d1 * i2h(v) - m1;  // dequantize.cuh:222-227
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = ((q.v[w] >> (4 * hsel)) & 0x0F0F0F0Fu) + (((qh.v[w] >> hbit) & 0x01010101u) << 4);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, d2 * u8pair_to_h2(v4, pr) - m2);  // dequantize.cuh:222-227
     }
   }
 };
@@ -178,30 +198,37 @@ template <> struct Decode<GGQ_TYPE_Q6_K> {
   }
 };
 
-template <int T>
+// CH = consecutive 8-element chunks per thread (1 or 2).  Two chunks of the same 16-element run share the block
+// header loads and the sub-scale decode (the compiler merges them), which is what bounded Q3_K / Q6_K.
+template <int T, int CH>
 __global__ void __launch_bounds__(256) dequant_kernel(const uint8_t* __restrict__ w,
                                                       _Float16* __restrict__ out,
                                                       int64_t n_chunks) {
   constexpr int CPB = Fmt<T>::QK / 8;  // 8-element chunks per block
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= n_chunks) return;
-  const int64_t ib = c / CPB;
-  const int sub = (int)(c - ib * CPB);
-  _Float16 y[8];
-  Decode<T>::run(w + ib * Fmt<T>::BS, sub, y);
-  h8 v;
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CH;
+  if (c0 >= n_chunks) return;          // n_chunks % CH == 0: every block has an even number of chunks
+  const int64_t ib = c0 / CPB;
+  const int sub = (int)(c0 - ib * CPB);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = y[i];
-  *(h8*)(out + c * 8) = v;
+  for (int i = 0; i < CH; ++i) {
+    _Float16 y[8];
+    Decode<T>::run(w + ib * Fmt<T>::BS, sub + i, y);
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = y[e];
+    *(h8*)(out + (c0 + i) * 8) = v;
+  }
 }
 
 template <int T>
 static int launch_dequant(const void* w, void* out, int64_t k, hipStream_t s) {
+  constexpr int CH = GGQ_DEQUANT_CH(T);
   const int64_t n_chunks = k / 8;
   if (n_chunks == 0) return GGQ_OK;
-  const int64_t grid = (n_chunks + 255) / 256;
+  const int64_t n_threads = n_chunks / CH;   // QK / 8 is 4 or 32: divisible by CH
+  const int64_t grid = (n_threads + 255) / 256;
   if (grid > 0x7fffffffLL) return GGQ_ERR_SHAPE;
-  hipLaunchKernelGGL(dequant_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s,
+  hipLaunchKernelGGL((dequant_kernel<T, CH>), dim3((unsigned)grid), dim3(256), 0, s,
                      (const uint8_t*)w, (_Float16*)out, n_chunks);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
