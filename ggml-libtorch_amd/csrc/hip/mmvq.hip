@@ -418,8 +418,8 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
   rpw = (rpw + ROWS - 1) / ROWS * ROWS;
   const int64_t waves = (n + rpw - 1) / rpw;
   int64_t grid = (waves + 3) / 4;
-  if (FUSED) {   // one 16-wave workgroup per CU (fewer when there are fewer than 2 rows per wave)
-    grid = (n + 31) / 32;
+  if (FUSED) {   // one 16-wave workgroup per CU (fewer when there is less than one row per wave)
+    grid = (n + 15) / 16;   // at least one row per wave before a CU is left without a workgroup
     grid = grid > 256 ? 256 : grid;
   }
   auto kern = mmvq_kernel<T, DT, ROWS, FUSED>;
