@@ -27,7 +27,7 @@ namespace ggq {
 
 __device__ __forceinline__ _Float16 i2h(int v) { return (_Float16)v; }  // __int2half_rn
 
-// Packed path of the K-quant decoders: the integer field extraction runs on four bytes per dword, the bytes
+// Packed path of the decoders: the integer field extraction runs on four bytes per dword, the bytes
 // (0..255, exact in fp16) become half2 pairs via v_cvt_f32_ubyteN + v_cvt_pkrtz_f16_f32, and every __hmul / __hsub
 // of the reference is a v_pk_*_f16 on two elements â€” the same IEEE operation per element, half the vector
 // instructions (these formats were VALU-bound at 55-62 % of the HBM roof with the scalar sequence).
@@ -36,6 +36,8 @@ __device__ __forceinline__ h2 u8pair_to_h2(uint32_t p, int pair) {   // bytes 2Â
   return __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 __device__ __forceinline__ void st_h2(_Float16* y, int i, h2 v) { y[i] = v[0]; y[i + 1] = v[1]; }
+// bit k (k = 0..3) of x -> bit 0 of byte k (the four partial products do not overlap)
+__device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x) { return ((x & 0xF) * 0x00204081u) & 0x01010101u; }
 
 // ---- per-format decode of the 8-element chunk `sub` of one block -----------
 template <int T> struct Decode;
@@ -46,10 +48,12 @@ template <> struct Decode<GGQ_TYPE_Q4_0> {
     const _Float16 d = bits_h(ld_u16(b + off::Q4_0_D));
     const u32x2_a2 q = ld_u32x2(b + off::Q4_0_QS + 8 * (sub & 1));
     const int sh = 4 * (sub >> 1);
+    const h2 d2 = {d, d}, off2 = {(_Float16)8.0f, (_Float16)8.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int n = (q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF;
-      y[i] = (i2h(n) - (_Float16)8.0f) * d;  // dequantize.cuh:11-15
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = (q.v[w] >> sh) & 0x0F0F0F0Fu;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, (u8pair_to_h2(v4, pr) - off2) * d2);  // dequantize.cuh:11-15
     }
   }
 };
@@ -59,10 +63,12 @@ template <> struct Decode<GGQ_TYPE_Q4_1> {
     const _Float16 d = bits_h(dm & 0xFFFF), m = bits_h(dm >> 16);
     const u32x2_a2 q = ld_u32x2(b + off::Q4_1_QS + 8 * (sub & 1));
     const int sh = 4 * (sub >> 1);
+    const h2 d2 = {d, d}, m2 = {m, m};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int n = (q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF;
-      y[i] = i2h(n) * d + m;  // dequantize.cuh:27-31
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = (q.v[w] >> sh) & 0x0F0F0F0Fu;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, u8pair_to_h2(v4, pr) * d2 + m2);  // dequantize.cuh:27-31
     }
   }
 };
@@ -72,10 +78,12 @@ template <> struct Decode<GGQ_TYPE_Q5_0> {
     const uint32_t qh = ld_u32(b + off::Q5_0_QH) >> (8 * sub);  // element e <- bit e
     const u32x2_a2 q = ld_u32x2(b + off::Q5_0_QS + 8 * (sub & 1));
     const int sh = 4 * (sub >> 1);
+    const h2 d2 = {d, d}, off2 = {(_Float16)16.0f, (_Float16)16.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int n = ((q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF) | (((qh >> i) & 1) << 4);
-      y[i] = (i2h(n) - (_Float16)16.0f) * d;  // dequantize.cuh:45-49
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = ((q.v[w] >> sh) & 0x0F0F0F0Fu) | bits4_to_bytes(qh >> (4 * w)) << 4;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, (u8pair_to_h2(v4, pr) - off2) * d2);  // dequantize.cuh:45-49
     }
   }
 };
@@ -86,10 +94,12 @@ template <> struct Decode<GGQ_TYPE_Q5_1> {
     const uint32_t qh = ld_u32(b + off::Q5_1_QH) >> (8 * sub);
     const u32x2_a2 q = ld_u32x2(b + off::Q5_1_QS + 8 * (sub & 1));
     const int sh = 4 * (sub >> 1);
+    const h2 d2 = {d, d}, m2 = {m, m};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int n = ((q.v[i >> 2] >> (8 * (i & 3) + sh)) & 0xF) | (((qh >> i) & 1) << 4);
-      y[i] = i2h(n) * d + m;  // dequantize.cuh:64-68
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = ((q.v[w] >> sh) & 0x0F0F0F0Fu) | bits4_to_bytes(qh >> (4 * w)) << 4;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, u8pair_to_h2(v4, pr) * d2 + m2);  // dequantize.cuh:64-68
     }
   }
 };
@@ -97,10 +107,12 @@ template <> struct Decode<GGQ_TYPE_Q8_0> {
   static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
     const _Float16 d = bits_h(ld_u16(b + off::Q8_0_D));
     const u32x2_a2 q = ld_u32x2(b + off::Q8_0_QS + 8 * sub);
+    const h2 d2 = {d, d}, bias2 = {(_Float16)128.0f, (_Float16)128.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int n = (int8_t)(q.v[i >> 2] >> (8 * (i & 3)));
-      y[i] = i2h(n) * d;  // dequantize.cuh:74-77
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t u4 = q.v[w] ^ 0x80808080u;   // int8 + 128 as unsigned bytes; minus 128 in fp16 is exact
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, (u8pair_to_h2(u4, pr) - bias2) * d2);  // dequantize.cuh:74-77
     }
   }
 };
@@ -115,10 +127,12 @@ template <> struct Decode<GGQ_TYPE_Q2_K> {
     const int sc = b[off::Q2_K_SC + (sub >> 1)];  // scale of the 16-element group e/16
     const u32x2_a2 q = ld_u32x2(b + off::Q2_K_QS + 32 * n + l0);
     const _Float16 mterm = dmin * i2h(sc >> 4);
+    const h2 d2 = {dall, dall}, m2 = {mterm, mterm};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int v = (q.v[i >> 2] >> (8 * (i & 3) + 2 * j)) & 3;
-      y[i] = dall * i2h((sc & 0xF) * v) - mterm;  // dequantize.cuh:117-120
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = ((q.v[w] >> (2 * j)) & 0x03030303u) * (uint32_t)(sc & 0xF);   // bytes <= 45: no carries
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, d2 * u8pair_to_h2(v4, pr) - m2);  // dequantize.cuh:117-120
     }
   }
 };
@@ -189,11 +203,14 @@ template <> struct Decode<GGQ_TYPE_Q6_K> {
     const int sc = (int8_t)b[off::Q6_K_SC + (sub >> 1)];
     const u32x2_a2 ql = ld_u32x2(b + off::Q6_K_QL + 64 * ip + 32 * (j & 1) + l0);
     const u32x2_a2 qh = ld_u32x2(b + off::Q6_K_QH + 32 * ip + l0);
+    // i2h(scÂ·(q-32)) = one round-to-nearest of an exact integer product = the fp16 product of the exact halves
+    const h2 d2 = {d, d}, sc2 = {i2h(sc), i2h(sc)}, off2 = {(_Float16)32.0f, (_Float16)32.0f}, zero2 = {(_Float16)0.0f, (_Float16)0.0f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int lo = (ql.v[i >> 2] >> (8 * (i & 3) + 4 * (j >> 1))) & 0xF;
-      const int hi = (qh.v[i >> 2] >> (8 * (i & 3) + 2 * j)) & 3;
-      y[i] = d * i2h(sc * ((lo | (hi << 4)) - 32));  // dequantize.cuh:250-253
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t v4 = ((ql.v[w] >> (4 * (j >> 1))) & 0x0F0F0F0Fu) | (((qh.v[w] >> (2 * j)) & 0x03030303u) << 4);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)   // (+0: the integer product 0 converts to +0, scÂ·(+0) would be -0 for sc < 0)
+        st_h2(y, 4 * w + 2 * pr, d2 * (sc2 * (u8pair_to_h2(v4, pr) - off2) + zero2));  // dequantize.cuh:250-253
     }
   }
 };
