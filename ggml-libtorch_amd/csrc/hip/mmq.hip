@@ -75,8 +75,9 @@ __device__ __forceinline__ float as_f32(int v) { return __builtin_bit_cast(float
 __device__ __forceinline__ uint32_t sub_bytes(uint32_t x, uint32_t c4) {
   return ((x | 0x80808080u) - c4) ^ 0x80808080u;
 }
+// bit k (k = 0..3) of x -> bit 4 of byte k: the four partial products of the multiply do not overlap
 __device__ __forceinline__ uint32_t spread4b(uint32_t x) {
-  return ((x & 1) << 4) | ((x & 2) << 11) | ((x & 4) << 18) | ((x & 8) << 25);
+  return (((x & 0xF) * 0x00204081u) & 0x01010101u) << 4;
 }
 
 // Raw bytes of one 32-element weight group as loaded from global memory (prefetch registers);
@@ -185,18 +186,23 @@ __device__ __forceinline__ void unpack_raw(const Raw& r, int G, uint32_t w[8], u
   } else if constexpr (T == GGQ_TYPE_Q3_K) {
     const int j = gl & 3;
     const int sc0 = q3k_scale(r.s[0], r.s[1], r.s[2], 2 * gl), sc1 = q3k_scale(r.s[0], r.s[1], r.s[2], 2 * gl + 1);
-    // tile holds -(q3 * sc) in [-128, 124] (q3*sc itself reaches +128); the sign goes into s0
+    // tile holds -(q3 * sc) in [-128, 124] (q3*sc itself reaches +128); the sign goes into s0.  Four bytes at a
+    // time: b = q2 + 4·h in 0..7 (q3 = b - 4), u = b·|sc| (one packed 16-bit multiply: b1·|sc|·256 + b0·|sc| < 2^16),
+    // c = 4·|sc|, and -(q3·sc) = (4 - b)·sc = c - u for sc >= 0, u - c for sc < 0, as a per-byte subtraction.
+    auto tile4 = [&](uint32_t q, uint32_t hm, int sc) {
+      const uint32_t b4 = ((q >> (2 * j)) & 0x03030303u) + (((hm >> gl) & 0x01010101u) << 2);
+      const uint32_t a = (uint32_t)(sc < 0 ? -sc : sc);
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      const us2 prod = __builtin_bit_cast(us2, b4) * us2{(unsigned short)a, (unsigned short)a};
+      const uint32_t u = __builtin_bit_cast(uint32_t, prod), c = 0x04040404u * a;
+      const uint32_t x = sc < 0 ? u : c, y = sc < 0 ? c : u;
+      constexpr uint32_t H = 0x80808080u;
+      return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);   // x - y per byte, no borrow between bytes
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint32_t o0 = 0, o1 = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int v0 = (int)((r.q[0].v[i] >> (8 * c + 2 * j)) & 3) - (((r.q[2].v[i] >> (8 * c + gl)) & 1) ? 0 : 4);
-        const int v1 = (int)((r.q[1].v[i] >> (8 * c + 2 * j)) & 3) - (((r.q[3].v[i] >> (8 * c + gl)) & 1) ? 0 : 4);
-        o0 |= (uint32_t)((-(v0 * sc0)) & 0xFF) << (8 * c);
-        o1 |= (uint32_t)((-(v1 * sc1)) & 0xFF) << (8 * c);
-      }
-      w[i] = o0; w[4 + i] = o1;
+      w[i] = tile4(r.q[0].v[i], r.q[2].v[i], sc0);
+      w[4 + i] = tile4(r.q[1].v[i], r.q[3].v[i], sc1);
     }
     s0 = -bits_h_f32(r.s[3]);
   } else if constexpr (T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K) {

@@ -55,8 +55,8 @@ __device__ __forceinline__ int dot16(const uint32_t v[4], v4i a) {
 }
 
 // spread the low 4 bits of x to bit 4 of the four bytes of a dword
-__device__ __forceinline__ uint32_t spread4(uint32_t x) {
-  return ((x & 1) << 4) | ((x & 2) << 11) | ((x & 4) << 18) | ((x & 8) << 25);
+__device__ __forceinline__ uint32_t spread4(uint32_t x) {   // one multiply: the four partial products do not overlap
+  return (((x & 0xF) * 0x00204081u) & 0x01010101u) << 4;
 }
 
 // UnitDot<T>::run(row pointer, unit index u, activations) -> this lane's partial sum.
