@@ -269,6 +269,25 @@ def test_mmq_transposed_shape_rows_sample(oracle, t):
         util.assert_fp_accumulate(y[:, torch.from_numpy(rows).cuda()], ref, yabs, torch.float16, f"mmq transposed {t.name} b={batch}")
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q6_K, GGMLType.Q4_0, GGMLType.Q5_K], ids=lambda t: t.name)
+@pytest.mark.parametrize("batch", [1, 8, 128])
+def test_power_of_two_scaling_full_size(t, batch):
+    """Size-independent exactness property at the BASELINE shape (no oracle needed): scaling X by 2^k scales every
+    Q8_1 block scale and block sum by exactly 2^k and leaves the int8 codes unchanged, so Y scales by exactly 2^k
+    (fp32 in/out; all values stay far from fp16's range limits for k = +-3).  Covers the GEMV, small-batch and
+    64-token-unit launches on all 11008 x 4096 outputs.  (Not a property of Q4_1 / Q5_1: the reference multiplies their
+    scales in fp16, `__hmul2(dm, ds8)`, and those products sit at the edge of fp16's subnormal range.)"""
+    n_rows, k = 11008, 4096
+    w = synth.random_weight(t, n_rows, k, seed=51)
+    x = _x((batch, k), torch.float32, seed=52)
+    f = util.gpu_mmvq if batch == 1 else util.gpu_mmq
+    y = f(w, x, t, n_rows)
+    assert torch.isfinite(y).all()
+    for kk in (3, -3):
+        ys = f(w, x * (2.0 ** kk), t, n_rows)
+        assert torch.equal(ys, y * (2.0 ** kk)), f"{t.name} batch {batch}: Y(2^{kk} X) != 2^{kk} Y(X)"
+
+
 @pytest.mark.parametrize("batch", [1, 8, 128])
 def test_config5_shard_shape(oracle, batch):
     """BASELINE configs[4]: Q4_K 8192 x 28672 sharded over 8 GPUs = 3584 rows x K 8192 per rank, batch 1 / 8 / 128
