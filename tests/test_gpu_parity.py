@@ -288,6 +288,20 @@ def test_power_of_two_scaling_full_size(t, batch):
         assert torch.equal(ys, y * (2.0 ** kk)), f"{t.name} batch {batch}: Y(2^{kk} X) != 2^{kk} Y(X)"
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q5_1], ids=lambda t: t.name)
+@pytest.mark.parametrize("batch", [8, 16, 77, 128])
+def test_token_permutation_full_size(t, batch):
+    """Permuting the rows of X permutes the rows of Y bit-exactly: a token's result may not depend on its lane,
+    accumulator register (batch <= 16 variants), token block or 64-token unit.  Full BASELINE shape, no oracle."""
+    n_rows, k = 11008, 4096
+    w = synth.random_weight(t, n_rows, k, seed=61)
+    x = _x((batch, k), torch.float16, seed=62)
+    y = util.gpu_mmq(w, x, t, n_rows)
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(batch)).cuda()
+    y2 = util.gpu_mmq(w, x[perm].contiguous(), t, n_rows)
+    assert torch.equal(y2, y[perm]), f"{t.name} batch {batch}: Y(P X) != P Y(X)"
+
+
 @pytest.mark.parametrize("batch", [1, 8, 128])
 def test_config5_shard_shape(oracle, batch):
     """BASELINE configs[4]: Q4_K 8192 x 28672 sharded over 8 GPUs = 3584 rows x K 8192 per rank, batch 1 / 8 / 128
