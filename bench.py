@@ -212,22 +212,24 @@ def main():
         comm = torch.cuda.Stream(device=dev)
         ys = [torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
         gathered = [torch.empty((world * BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
-        done = [None, None]
+        # (events are created once and re-recorded: per-step host overhead matters at ~30 us of GPU work per step)
+        ready_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        done_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        used = [False, False]
+        main_stream = torch.cuda.current_stream()
 
         def step(i):
             b = i & 1
-            if done[b] is not None:
-                torch.cuda.current_stream().wait_event(done[b])  # slab b is free again
+            if used[b]:
+                main_stream.wait_event(done_ev[b])  # slab b is free again
             rc = L.ggq_mul_mat_q(vp(w), vp(x), vp(ys[b]), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
             assert rc == 0, rc
-            ready = torch.cuda.Event()
-            ready.record()
-            comm.wait_event(ready)
+            ready_ev[b].record(main_stream)
+            comm.wait_event(ready_ev[b])
             with torch.cuda.stream(comm):
                 dist.all_gather_into_tensor(gathered[b], ys[b])
-                ev = torch.cuda.Event()
-                ev.record()
-            done[b] = ev
+                done_ev[b].record(comm)
+            used[b] = True
 
         for i in range(args.warmup):
             step(i)
