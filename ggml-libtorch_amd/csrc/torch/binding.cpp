@@ -104,12 +104,10 @@ torch::Tensor ggml_mul_mat_a8(torch::Tensor W, torch::Tensor X, int64_t type, in
     Y = torch::empty({X.size(0), X.size(1), row}, options);
   }
   if (batch == 0 || row == 0) return Y;
-  const int64_t padded = ggq_mmq_padded_k(col);
-  // reference: {batch, padded/32*9} ints (mmq.cu:208); whole 32-token tiles here (fragment-major scratch)
-  TORCH_CHECK((size_t)((batch + 31) / 32 * 32) * (size_t)(padded / 32 * 36) == ggq_mmq_scratch_bytes(batch, col),
-              "ggml_mul_mat_a8: scratch size formula out of sync with ggq_mmq_scratch_bytes");
-  at::Tensor quant_X = torch::empty({(batch + 31) / 32 * 32, padded / 32 * 9},
-                                    torch::TensorOptions().dtype(torch::kInt32).device(W.device()));
+  // reference: {batch, padded/32*9} ints (mmq.cu:208); here whatever the kernel behind ggq_mul_mat_q needs
+  // (whole 32-token tiles; fp32 token scales + stream-K fix-up slots from batch 17): ggq_mmq_scratch_bytes
+  const int64_t scratch_ints = (int64_t)((ggq_mmq_scratch_bytes(batch, col) + 3) / 4);
+  at::Tensor quant_X = torch::empty({scratch_ints}, torch::TensorOptions().dtype(torch::kInt32).device(W.device()));
   const int rc = ggq_mul_mat_q(W.data_ptr(), X.data_ptr(), Y.data_ptr(), (int)type, dt, batch, col, row,
                                quant_X.data_ptr(), current_stream(X));
   TORCH_CHECK(rc == GGQ_OK, "ggml_mul_mat_a8: ", ggq_strerror(rc));

@@ -9,7 +9,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "mmq"
 t = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-K, N = 4096, 11008
+K, N = int(os.environ.get('K', 4096)), int(os.environ.get('N', 11008))
 L = ggqlib.hip()
 vp = lambda x: ctypes.c_void_p(x.data_ptr())
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
