@@ -7,10 +7,18 @@ One *step* = one pass of the hot path over one batch of synthetic input:
 with every input already resident in HBM.  `value` = algorithmic bytes (quantised W + X + Y,
 SURVEY.md §8d) of all steps of all ranks / wall time of the timed region, in GB/s.
 
+Cache state: consecutive steps use DIFFERENT weight tensors — a ring of N_COLD distinct
+25 MB copies (> 256 MB Infinity Cache + 32 MB L2 in total), the way the layers of a model follow each other — so
+every step streams its weights from HBM ("cold").  The same loop over ONE tensor (weights resident in
+L2 + Infinity Cache, "warm") is reported beside it as `value_warm`; every `extra` entry carries both states
+with median / p10 / p90 over repeated timings.
+
     python bench.py [--gpus N] [--steps K] [--warmup W]
 For N > 1 the driver starts it under torch.distributed.run (one rank per GPU, RCCL): every rank
 owns an 11008-row shard (weak scaling) and the [128, 11008] slabs are all-gathered each step
-on a side stream, overlapped with the next step's compute.
+on a side stream, overlapped with the next step's compute.  Rank 0 additionally reports the
+strong-scaling table of BASELINE configs[4] (Q4_K 28672 x 8192 row-sharded P ways, batch 1 / 8 / 128:
+kernel, collective and end-to-end times separately) under "strong_scaling_config5".
 
 Prints ONE JSON line on rank 0.  Besides the contract keys it carries
   "roofline":     dominant kernel (mul_mat_q) vs the 8 TB/s HBM roof, duration measured live
@@ -20,9 +28,11 @@ Prints ONE JSON line on rank 0.  Besides the contract keys it carries
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,9 +42,13 @@ sys.path.insert(0, os.path.join(ROOT, "ggml-libtorch_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (same guide: 2x the ~2.5 PF bf16 rate)
 Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 = 12, 13, 14, 2, 8
+NAMES = {Q4_K: "Q4_K", Q4_0: "Q4_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q6_K: "Q6_K"}
 K_DIM, N_DIM, BATCH = 4096, 11008, 128
+COLD_BYTES = 352 << 20   # distinct bytes a "cold" ring must span: 256 MiB Infinity Cache + 32 MiB L2 + margin
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def algo_bytes_matmul(t, n_rows, k, batch, esz=2):
@@ -55,26 +69,33 @@ def cur_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def time_launches(fn, iters, reps=5, use_graph=True):
-    """Average device time of one call of fn: `iters` back-to-back launches bracketed by HIP
-    events recorded on the stream the kernels run on (torch's current stream)."""
-    fn()
+def ring_of(t, nbytes_each, min_n=2):
+    """distinct device copies of tensor t whose total size exceeds the caches (cold ring)"""
+    n = max(min_n, -(-COLD_BYTES // max(1, nbytes_each)) + 1)
+    return [t] + [t.clone() for _ in range(n - 1)]
+
+
+def time_launches(fn, iters, reps=9, use_graph=True):
+    """Device time of one call of fn(i): `iters` back-to-back launches (i = 0..iters-1) bracketed by HIP
+    events recorded on the stream the kernels run on (torch's current stream), repeated `reps` times.
+    Returns {"us": median, "p10", "p90", "min"} of the per-launch averages."""
+    fn(0)
     torch.cuda.synchronize()
     runner = None
     if use_graph:
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for _ in range(iters):
-                    fn()
+                for i in range(iters):
+                    fn(i)
             runner = g.replay
         except Exception:  # pragma: no cover - capture unsupported: fall back to eager launches
             runner = None
             torch.cuda.synchronize()
     if runner is None:
         def runner():
-            for _ in range(iters):
-                fn()
+            for i in range(iters):
+                fn(i)
     runner()
     torch.cuda.synchronize()
     times = []
@@ -85,49 +106,211 @@ def time_launches(fn, iters, reps=5, use_graph=True):
         e1.record()
         e1.synchronize()
         times.append(e0.elapsed_time(e1) * 1e3 / iters)  # us per launch
-    return float(np.median(times)), float(np.min(times))
+    a = np.asarray(times)
+    return {"us": round(float(np.median(a)), 3), "p10": round(float(np.percentile(a, 10)), 3),
+            "p90": round(float(np.percentile(a, 90)), 3), "min": round(float(a.min()), 3)}
+
+
+def rates(stats, nbytes, ops=None):
+    us = stats["us"]
+    r = dict(stats)
+    r["GB/s"] = round(nbytes / (us * 1e-6) / 1e9, 1)
+    r["pct_hbm_roofline"] = round(100 * nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 2)
+    if ops:
+        r["TOP/s"] = round(ops / (us * 1e-6) / 1e12, 2)
+        r["pct_int8_mfma_peak"] = round(100 * ops / (us * 1e-6) / 1e12 / INT8_PEAK_TOPS, 2)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def _threads_available():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:  # pragma: no cover
+        return os.cpu_count() or 1
 
 
 def cpu_baseline(sample_rows=N_DIM):
-    """The oracle (C port of the reference's mul_mat_q algorithm) on one host core, on a bounded
-    sample of the same workload: `sample_rows` weight rows (default: all of them) x all 128 tokens."""
+    """The oracle (C port of the reference's mul_mat_q algorithm) on the host cores, on a bounded sample of the same
+    workload: `sample_rows` weight rows x all 128 tokens — one core (the reference's CPU code is single-threaded,
+    ggml-cpu/ggml-quants.hpp) and, beside it, the same loop row-partitioned over T threads."""
     from oracle import oracle as O
     from ggq import synth
-    w = synth.random_weight(Q4_K, sample_rows, K_DIM, seed=0)
+    w = np.ascontiguousarray(synth.random_weight(Q4_K, sample_rows, K_DIM, seed=0))
     x = torch.randn((BATCH, K_DIM), generator=torch.Generator().manual_seed(0)).half().float().numpy()
-    O.lib()
+    lib = O.lib()
     q8 = O.quantize_q8_1_mmq(x, Q4_K)
+
+    def run(r0, r1, y):
+        rc = lib.oracle_mul_mat_q(Q4_K, O._p(w[r0:r1]), O._p(q8), O._p(y), None, BATCH, K_DIM, r1 - r0)
+        assert rc == 0
+
     y = np.empty((BATCH, sample_rows), np.float32)
     t0 = time.perf_counter()
-    rc = O.lib().oracle_mul_mat_q(Q4_K, O._p(np.ascontiguousarray(w)), O._p(q8), O._p(y), None, BATCH, K_DIM,
-                                  sample_rows)
-    dt = time.perf_counter() - t0
-    assert rc == 0
+    run(0, sample_rows, y)
+    dt1 = time.perf_counter() - t0
     nbytes = algo_bytes_matmul(Q4_K, sample_rows, K_DIM, BATCH)
-    return {"value": round(nbytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"oracle_mul_mat_q (quantised X given), first {sample_rows} of {N_DIM} Q4_K rows x {BATCH} tokens, "
-                      f"K={K_DIM}, 1 pass, {dt:.2f} s", "host_cores_available": os.cpu_count()}
+    out = {"value": round(nbytes / dt1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": f"oracle_mul_mat_q (quantised X given), {sample_rows} of {N_DIM} Q4_K rows x {BATCH} tokens, "
+                     f"K={K_DIM}, 1 pass, {dt1:.2f} s", "host_cores_available": _threads_available()}
+    T = min(_threads_available(), 64)
+    if T > 1:
+        per = -(-sample_rows // T)
+        spans = [(i * per, min(sample_rows, (i + 1) * per)) for i in range(T) if i * per < sample_rows]
+        ys = [np.empty((BATCH, b - a), np.float32) for a, b in spans]
+        th = [threading.Thread(target=run, args=(a, b, yy)) for (a, b), yy in zip(spans, ys)]   # ctypes drops the GIL
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dtT = time.perf_counter() - t0
+        out["threads"] = {"value": round(nbytes / dtT / 1e9, 4), "unit": "GB/s", "cores": len(spans),
+                          "sample": f"the same rows partitioned over {len(spans)} threads, {dtT:.2f} s"}
+    return out
 
 
-def reference_cpu_dequant():
-    """BASELINE config 1 beside it: the reference's own compiled ggml-cpu op (oracle/_ref, when
-    it travelled) on Q4_0 4096x4096."""
+def cpu_config1():
+    """BASELINE configs[0]: Q4_0 dequantise 4096 x 4096 on the host — the reference's own compiled ggml-cpu op
+    (oracle/_ref, when it travelled), the product's custom_ops twin on 1 thread and on T threads."""
+    res = {}
+    from ggq import synth, lib as ggqlib
+    m = n = 4096
+    w_np = synth.random_weight(Q4_0, m, n, seed=0)
+    nb = m * n // 32 * 18 + m * n * 4
+    try:
+        from oracle import oracle as O
+        ref = O.load_reference_cpu_op()
+        if ref is not None:
+            w = torch.from_numpy(w_np)
+            ref.ggml_dequantize(w, Q4_0, m, n)
+            t0 = time.perf_counter()
+            ref.ggml_dequantize(w, Q4_0, m, n)
+            dt = time.perf_counter() - t0
+            res["reference_ggml_cpu_op"] = {"value": round(nb / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "reference",
+                                            "sample": f"reference custom_ops.ggml_dequantize Q4_0 4096x4096 -> fp32, {dt * 1e3:.1f} ms"}
+    except Exception as e:  # pragma: no cover
+        res["reference_ggml_cpu_op"] = {"error": str(e)[:200]}
+    try:
+        C = ggqlib.cpu()
+        out = np.empty((m, n), np.float32)
+        wb = np.ascontiguousarray(w_np)
+        for nt in (1, min(_threads_available(), 64)):
+            C.ggq_cpu_dequantize_f32(wb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), Q4_0, m, n, nt)
+            t0 = time.perf_counter()
+            rc = C.ggq_cpu_dequantize_f32(wb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), Q4_0, m, n, nt)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            res[f"product_custom_ops_{nt}_threads"] = {"value": round(nb / dt / 1e9, 3), "unit": "GB/s", "cores": nt, "kind": "product",
+                                                       "sample": f"ggq_cpu_dequantize_f32 Q4_0 4096x4096 -> fp32, {dt * 1e3:.1f} ms"}
+    except Exception as e:  # pragma: no cover
+        res["product_custom_ops"] = {"error": str(e)[:200]}
+    return res
+
+
+def cpu_torch_matmul():
+    """What the reference's tests compute as ground truth (HK/tests/kernels/test_cuda_kernels.py:71-74): x @ dequant(W).T in
+    fp32 torch on the host (threads = torch.get_num_threads()); the dequantised matrix is given (not timed)."""
     try:
         from oracle import oracle as O
         from ggq import synth
-        ref = O.load_reference_cpu_op()
-        if ref is None:
-            return None
-        w = torch.from_numpy(synth.random_weight(Q4_0, 4096, 4096, seed=0))
-        ref.ggml_dequantize(w, Q4_0, 4096, 4096)
+        rows = 2048   # bounded sample of the 11008 rows
+        w = synth.random_weight(Q4_K, rows, K_DIM, seed=0)
+        wd = torch.from_numpy(O.dequantize_f16(w, Q4_K, rows * K_DIM).astype(np.float32).reshape(rows, K_DIM))
+        x = torch.randn((BATCH, K_DIM), generator=torch.Generator().manual_seed(0))
+        x @ wd.T
         t0 = time.perf_counter()
-        ref.ggml_dequantize(w, Q4_0, 4096, 4096)
+        x @ wd.T
         dt = time.perf_counter() - t0
-        nb = 4096 * 4096 // 32 * 18 + 4096 * 4096 * 4
-        return {"value": round(nb / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "reference",
-                "sample": f"reference ggml-cpu custom_ops.ggml_dequantize Q4_0 4096x4096 -> fp32, {dt * 1e3:.1f} ms"}
+        return {"value": round(2.0 * BATCH * rows * K_DIM / dt / 1e9, 1), "unit": "GFLOP/s", "cores": torch.get_num_threads(),
+                "sample": f"fp32 torch x[128,4096] @ dequant(W)[{rows},4096].T on the host, {dt * 1e3:.1f} ms"}
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:200]}
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def strong_scaling_config5(L, dev, world, rank, dist):
+    """BASELINE configs[4]: Q4_K 28672 x 8192 row-sharded over P = world ranks; batch 1 / 8 / 128.
+    Rank r multiplies its 28672/P rows and writes the slab straight into slot r of a [P, batch, N/P] buffer
+    (ggq_mul_mat_q_ld / ggq_mul_mat_vec_q write through a row pitch, no staging copy), which is then all-gathered
+    IN PLACE (input = the rank's own slot of the output).  Kernel, collective and end-to-end are timed separately
+    with HIP events on the launch stream, eager launches, max over ranks."""
+    from ggq import synth
+    from ggq.dist import shard_rows
+    N5, K5 = 28672, 8192
+    s, e = shard_rows(N5, world, rank)
+    rows = e - s
+    w5 = torch.from_numpy(synth.random_weight(Q4_K, rows, K5, seed=100 + rank)).to(dev)
+    res = {"P": world, "rows_per_rank": rows, "k": K5, "quant_type": "Q4_K",
+           "backend": (dist.get_backend() if world > 1 else "none (single rank)"),
+           "world_size_seen_by_torch_distributed": (dist.get_world_size() if world > 1 else 1)}
+    for b in (1, 8, BATCH):
+        x = torch.randn((b, K5), generator=torch.Generator().manual_seed(5)).half().to(dev)
+        buf = torch.empty((world, b, rows), dtype=torch.float16, device=dev)
+        mine = buf[rank]
+        sc = torch.empty(max(int(L.ggq_mmq_scratch_bytes(b, K5)), int(L.ggq_mmvq_scratch_bytes(K5))), dtype=torch.uint8, device=dev)
+
+        def kernel():
+            if b == 1:
+                rc = L.ggq_mul_mat_vec_q(vp(w5), vp(x), vp(mine), Q4_K, 1, K5, rows, vp(sc), cur_stream())
+            else:
+                rc = L.ggq_mul_mat_q_ld(vp(w5), vp(x), vp(mine), Q4_K, 1, b, K5, rows, rows, vp(sc), cur_stream())
+            assert rc == 0, rc
+
+        def collective():
+            if world > 1:
+                dist.all_gather_into_tensor(buf.view(world * b, rows), mine)
+
+        def both():
+            kernel()
+            collective()
+
+        entry = {}
+        for name, fn in (("kernel", kernel), ("collective", collective), ("end_to_end", both)):
+            if name == "collective" and world == 1:
+                entry[name] = {"us": 0.0}
+                continue
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            iters = 50
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            if world > 1:
+                tt = torch.tensor([us], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                us = float(tt.item())
+            entry[name] = {"us": round(us, 2)}
+        nbytes = algo_bytes_matmul(Q4_K, N5, K5, b)
+        entry["end_to_end"]["GB/s_whole_job"] = round(nbytes / (entry["end_to_end"]["us"] * 1e-6) / 1e9, 1)
+        entry["message_bytes_per_rank"] = b * rows * 2
+        entry["timing"] = "eager launches, HIP events, 50 iterations, max over ranks (includes host launch overhead at batch 1)"
+        res[f"batch{b}"] = entry
+    if world == 1:
+        # on a one-GPU box: what ONE rank of the 8-way split computes (3584 rows), kernel only, graph-timed — the
+        # compute side of the P = 8 column; its collective needs the 8-GPU node
+        rows8 = N5 // 8
+        w8 = w5[:rows8]
+        proj = {}
+        for b in (1, 8, BATCH):
+            x = torch.randn((b, K5), generator=torch.Generator().manual_seed(5)).half().to(dev)
+            y = torch.empty((b, rows8), dtype=torch.float16, device=dev)
+            sc = torch.empty(max(int(L.ggq_mmq_scratch_bytes(b, K5)), int(L.ggq_mmvq_scratch_bytes(K5))), dtype=torch.uint8, device=dev)
+            if b == 1:
+                fn = lambda i: L.ggq_mul_mat_vec_q(vp(w8), vp(x), vp(y), Q4_K, 1, K5, rows8, vp(sc), cur_stream())
+            else:
+                fn = lambda i: L.ggq_mul_mat_q(vp(w8), vp(x), vp(y), Q4_K, 1, b, K5, rows8, vp(sc), cur_stream())
+            proj[f"batch{b}"] = rates(time_launches(fn, 104), algo_bytes_matmul(Q4_K, rows8, K5, b), 2.0 * b * rows8 * K5)
+            proj[f"batch{b}"]["cache_state"] = "warm: one 16.5 MB shard"
+        res["one_rank_of_8_shard_3584x8192_kernel_only"] = proj
+    return res
 
 
 def main():
@@ -162,8 +345,9 @@ def main():
     from ggq import lib as ggqlib, synth
     L = ggqlib.hip()
 
-    # ---- workload: per-rank shard, inputs resident in HBM ----
+    # ---- workload: per-rank shard, inputs resident in HBM; a ring of distinct weight copies for the cold steps ----
     w = torch.from_numpy(synth.random_weight(Q4_K, N_DIM, K_DIM, seed=rank)).to(dev)
+    w_ring = ring_of(w, w.numel())
     x = torch.randn((BATCH, K_DIM), generator=torch.Generator().manual_seed(0)).half().to(dev)
     scratch = torch.empty(int(L.ggq_mmq_scratch_bytes(BATCH, K_DIM)), dtype=torch.uint8, device=dev)
     bytes_per_step = algo_bytes_matmul(Q4_K, N_DIM, K_DIM, BATCH)
@@ -172,45 +356,53 @@ def main():
         if world > 1:
             dist.barrier()
 
+    value_warm = None
     if world == 1:
         y = torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev)
 
-        def step():
-            rc = L.ggq_mul_mat_q(vp(w), vp(x), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
+        def step(i, ring=w_ring):
+            rc = L.ggq_mul_mat_q(vp(ring[i % len(ring)]), vp(x), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
             assert rc == 0, rc
 
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        graph = None
-        if not args.eager:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    for _ in range(args.steps):
-                        step()
-                graph.replay()  # instantiate / upload once, untimed
-                torch.cuda.synchronize()
-            except Exception as e:  # pragma: no cover
-                print(f"[bench] graph capture failed ({e}); timing eager launches", file=sys.stderr)
-                graph = None
-                torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if graph is not None:
-            graph.replay()
-        else:
-            for _ in range(args.steps):
-                step()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        launch_mode = "hipGraph replay of all steps" if graph is not None else "eager launches"
+        def timed(ring):
+            for i in range(args.warmup):
+                step(i, ring)
+            torch.cuda.synchronize()
+            graph = None
+            if not args.eager:
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        for i in range(args.steps):
+                            step(i, ring)
+                    graph.replay()  # instantiate / upload once, untimed
+                    torch.cuda.synchronize()
+                except Exception as e:  # pragma: no cover
+                    print(f"[bench] graph capture failed ({e}); timing eager launches", file=sys.stderr)
+                    graph = None
+                    torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if graph is not None:
+                graph.replay()
+            else:
+                for i in range(args.steps):
+                    step(i, ring)
+            torch.cuda.synchronize()
+            barrier()
+            return time.perf_counter() - t0, graph is not None
+
+        elapsed_warm, _ = timed([w])          # untimed for the headline: the warm twin, reported beside it
+        value_warm = bytes_per_step * args.steps / elapsed_warm / 1e9
+        elapsed, graphed = timed(w_ring)      # the headline: EXACTLY args.steps steps, weights streamed from HBM
+        launch_mode = "hipGraph replay of all steps" if graphed else "eager launches"
     else:
         # rank-local slab + all-gather on a side stream, double buffered
         comm = torch.cuda.Stream(device=dev)
         ys = [torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
+        # gather buffers in the [P, batch, rows] form (slot r = rank r's [batch, rows] slab; ggq.dist.unpermute_gathered
+        # turns it into [batch, P * rows] where a consumer needs that layout)
         gathered = [torch.empty((world * BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
         # (events are created once and re-recorded: per-step host overhead matters at ~30 us of GPU work per step)
         ready_ev = [torch.cuda.Event(), torch.cuda.Event()]
@@ -222,7 +414,7 @@ def main():
             b = i & 1
             if used[b]:
                 main_stream.wait_event(done_ev[b])  # slab b is free again
-            rc = L.ggq_mul_mat_q(vp(w), vp(x), vp(ys[b]), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
+            rc = L.ggq_mul_mat_q(vp(w_ring[i % len(w_ring)]), vp(x), vp(ys[b]), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
             assert rc == 0, rc
             ready_ev[b].record(main_stream)
             comm.wait_event(ready_ev[b])
@@ -261,112 +453,128 @@ def main():
                    "quant_type": "Q4_K", "k": K_DIM, "n_rows_per_gpu": N_DIM, "batch": BATCH,
                    "algorithmic_bytes_per_step_per_gpu": bytes_per_step,
                    "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of [128 x 11008] slabs" if world > 1 else ""),
-                   "launch": launch_mode, "cache_state": "warm loop over one 25 MB weight tensor (fits L2+MALL)"},
+                   "launch": launch_mode,
+                   "cache_state": f"cold: consecutive steps cycle {len(w_ring)} distinct weight tensors "
+                                  f"({len(w_ring) * w.numel() >> 20} MiB > 256 MiB Infinity Cache + 32 MiB L2)"},
         "pct_hbm_roofline": round(100.0 * value / world / HBM_PEAK_GBS, 2),
     }
+    if value_warm is not None:
+        out["value_warm"] = round(value_warm, 2)
+        out["config"]["cache_state_value_warm"] = "warm: every step re-reads ONE 25 MB weight tensor (resident in L2 + Infinity Cache)"
+    if world > 1:
+        out["config"]["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
 
     if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel (mul_mat_q alone, activations pre-quantised) ----
+        # ---- roofline of the dominant kernel (mul_mat_q alone, activations pre-quantised), cold weights ----
         # (the fused op quantises into the fragment-major scratch and runs the streamed kernel for Q4_K:
         #  time exactly that kernel, through the exported pre-quantised entry point)
         rc = L.ggq_quantize_q8_1_tiled(vp(x), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
         assert rc == 0
 
-        def mmq_only():
-            L.ggq_mul_mat_q_pretiled(vp(w), vp(scratch), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+        def mmq_only(i, ring=w_ring):
+            L.ggq_mul_mat_q_pretiled(vp(ring[i % len(ring)]), vp(scratch), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
 
-        us_med, us_min = time_launches(mmq_only, 200, use_graph=not args.eager)
-        achieved = bytes_per_step / (us_med * 1e-6) / 1e9
-        traffic = None  # PMC-derived HBM bytes per launch, measured offline with rocprofv3 (profiles/)
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["mmq_q4_k_batch128"]["hbm_bytes_per_launch"]
+        st_cold = time_launches(mmq_only, 208, use_graph=not args.eager)
+        st_warm = time_launches(lambda i: mmq_only(i, [w]), 208, use_graph=not args.eager)
+        achieved = bytes_per_step / (st_cold["us"] * 1e-6) / 1e9
+        ops = 2.0 * BATCH * N_DIM * K_DIM
+        traffic, traffic_note = None, "profiles/r02_traffic.json absent"
+        try:   # PMC-derived HBM bytes per launch, measured offline with rocprofv3 (profiles/); refused when the kernel changed since
+            tj = json.load(open(TRAFFIC_JSON))
+            src = hashlib.sha256(open(os.path.join(ROOT, "ggml-libtorch_amd", "csrc", "hip", "mmq.hip"), "rb").read()).hexdigest()
+            if tj.get("mmq_hip_sha256") == src:
+                traffic, traffic_note = tj["mmq_q4_k_batch128"]["hbm_bytes_per_launch"], tj["mmq_q4_k_batch128"].get("how", "")
+            else:
+                traffic_note = "profiles/r02_traffic.json was measured on a different mmq.hip (sha mismatch): stale, not reported"
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "kernel": "ggq::mmq_stream_kernel<Q4_K, f16, TB=2> (32 rows x 64 tokens x 4 K-slices per workgroup)",
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "avg_launch_us": round(us_med, 3), "min_launch_us": round(us_min, 3),
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                           "avg_launch_us": st_cold["us"], "p10_launch_us": st_cold["p10"], "p90_launch_us": st_cold["p90"],
+                           "min_launch_us": st_cold["min"], "cache_state": out["config"]["cache_state"],
+                           "warm": {"avg_launch_us": st_warm["us"], "p10": st_warm["p10"], "p90": st_warm["p90"],
+                                    "frac": round(bytes_per_step / (st_warm["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                            "algorithmic_bytes_per_launch": bytes_per_step,
-                           "int8_mfma_TOPs": round(2.0 * BATCH * N_DIM * K_DIM / (us_med * 1e-6) / 1e12, 2),
-                           "note": "duration = HIP-event time of 200 back-to-back launches / 200 on the launch stream"}
+                           "limiter": "vector-instruction issue (2 FMAs per (row, token, 32-group) triple), not HBM and not the matrix pipe: DESIGN.md §5.4",
+                           "int8_mfma_TOPs": round(ops / (st_cold["us"] * 1e-6) / 1e12, 2),
+                           "frac_int8_mfma_peak": round(ops / (st_cold["us"] * 1e-6) / 1e12 / INT8_PEAK_TOPS, 4),
+                           "note": "duration = HIP-event time of 208 back-to-back launches / 208 on the launch stream, median of 9 repeats"}
         if not args.no_extra:
-            out["extra"] = secondary_configs(L, dev, w, x, scratch, args)
+            out["extra"] = secondary_configs(L, dev, w, w_ring, x, scratch, args)
+            out["strong_scaling_config5"] = strong_scaling_config5(L, dev, world, rank, dist)
             out["cpu_baseline"] = cpu_baseline()
-            ref = reference_cpu_dequant()
-            if ref:
-                out["cpu_reference_dequant_q4_0_4096x4096"] = ref
+            out["cpu_config1_q4_0_dequant_4096x4096"] = cpu_config1()
+            out["cpu_torch_matmul_on_dequantised"] = cpu_torch_matmul()
+    elif world > 1 and not args.no_extra:
+        ss = strong_scaling_config5(L, dev, world, rank, dist)   # collective: every rank takes part
+        if rank == 0:
+            out["strong_scaling_config5"] = ss
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def secondary_configs(L, dev, w_q4k, x128, scratch, args):
-    """The other BASELINE configs on the same GPU, kernel-level (HIP events, graph replay)."""
+def secondary_configs(L, dev, w_q4k, w_q4k_ring, x128, scratch, args):
+    """The other BASELINE configs on the same GPU, kernel-level (HIP events, graph replay), each warm AND cold."""
     from ggq import synth
     res = {}
     g = not args.eager
 
-    def rec(name, us, nbytes, ops=None):
-        r = {"us": round(us, 3), "GB/s": round(nbytes / (us * 1e-6) / 1e9, 1),
-             "pct_hbm_roofline": round(100 * nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 2)}
-        if ops:
-            r["TOP/s"] = round(ops / (us * 1e-6) / 1e12, 2)
-        res[name] = r
+    def rec(name, make_fn, rings, nbytes, ops=None, iters=104):
+        """make_fn(bufs) -> launch using one buffer of each ring; cold cycles the rings, warm pins their first buffer"""
+        cold = time_launches(lambda i: make_fn([r[i % len(r)] for r in rings]), iters, use_graph=g)
+        warm = time_launches(lambda i: make_fn([r[0] for r in rings]), iters, use_graph=g)
+        entry = rates(warm, nbytes, ops)
+        entry["cache_state"] = "warm: one buffer re-used by every launch (L2 + Infinity Cache resident where it fits)"
+        entry["cold"] = rates(cold, nbytes, ops)
+        span = sum(len(r) * r[0].numel() * r[0].element_size() for r in rings) >> 20
+        entry["cold"]["cache_state"] = f"cold: launches cycle distinct buffers spanning {span} MiB"
+        res[name] = entry
 
-    out16 = torch.empty((N_DIM, K_DIM), dtype=torch.float16, device=dev)
     ws = {Q4_K: w_q4k}
     for t in (Q4_0, Q8_0, Q5_K, Q6_K):
         ws[t] = torch.from_numpy(synth.random_weight(t, N_DIM, K_DIM, seed=1)).to(dev)
-    names = {Q4_K: "Q4_K", Q4_0: "Q4_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q6_K: "Q6_K"}
-    # config 2: dequantise 11008 x 4096 -> fp16
+    rings = {t: (w_q4k_ring if t == Q4_K else ring_of(ws[t], ws[t].numel())) for t in ws}
+    # config 2: dequantise 11008 x 4096 -> fp16 (the 90 MB output cycles over 4 buffers in the cold run)
+    out_ring = [torch.empty((N_DIM, K_DIM), dtype=torch.float16, device=dev) for _ in range(4)]
     for t in (Q4_0, Q8_0, Q4_K):
-        us, _ = time_launches(lambda: L.ggq_dequantize_f16(vp(ws[t]), vp(out16), t, N_DIM, K_DIM, cur_stream()), 50, use_graph=g)
-        rec(f"dequantize_{names[t]}_11008x4096", us, algo_bytes_dequant(t, N_DIM, K_DIM))
+        rec(f"dequantize_{NAMES[t]}_11008x4096",
+            lambda b, t=t: L.ggq_dequantize_f16(vp(b[0]), vp(b[1]), t, N_DIM, K_DIM, cur_stream()),
+            [rings[t], out_ring], algo_bytes_dequant(t, N_DIM, K_DIM), iters=52)
+    del out_ring
     # config 3: MMVQ batch 1 (quantize_q8_1 + mul_mat_vec_q)
     x1 = x128[:1].contiguous()
     y1 = torch.empty((1, N_DIM), dtype=torch.float16, device=dev)
     sc1 = torch.empty(int(L.ggq_mmvq_scratch_bytes(K_DIM)), dtype=torch.uint8, device=dev)
     for t in (Q4_0, Q4_K):
-        us, _ = time_launches(lambda: L.ggq_mul_mat_vec_q(vp(ws[t]), vp(x1), vp(y1), t, 1, K_DIM, N_DIM, vp(sc1), cur_stream()), 200, use_graph=g)
-        rec(f"mmvq_{names[t]}_batch1", us, algo_bytes_matmul(t, N_DIM, K_DIM, 1), 2.0 * N_DIM * K_DIM)
+        rec(f"mmvq_{NAMES[t]}_batch1",
+            lambda b, t=t: L.ggq_mul_mat_vec_q(vp(b[0]), vp(x1), vp(y1), t, 1, K_DIM, N_DIM, vp(sc1), cur_stream()),
+            [rings[t]], algo_bytes_matmul(t, N_DIM, K_DIM, 1), 2.0 * N_DIM * K_DIM, iters=208)
     # config 4: MMQ batch 128 other formats; batch 8 for Q4_K and Q8_0
     y128 = torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev)
     for t in (Q5_K, Q6_K, Q8_0, Q4_0):
-        us, _ = time_launches(lambda: L.ggq_mul_mat_q(vp(ws[t]), vp(x128), vp(y128), t, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream()), 100, use_graph=g)
-        rec(f"mmq_{names[t]}_batch128", us, algo_bytes_matmul(t, N_DIM, K_DIM, BATCH), 2.0 * BATCH * N_DIM * K_DIM)
+        rec(f"mmq_{NAMES[t]}_batch128",
+            lambda b, t=t: L.ggq_mul_mat_q(vp(b[0]), vp(x128), vp(y128), t, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream()),
+            [rings[t]], algo_bytes_matmul(t, N_DIM, K_DIM, BATCH), 2.0 * BATCH * N_DIM * K_DIM)
     x8 = x128[:8].contiguous()
     for t in (Q4_K, Q8_0):
-        us, _ = time_launches(lambda: L.ggq_mul_mat_q(vp(ws[t]), vp(x8), vp(y128), t, 1, 8, K_DIM, N_DIM, vp(scratch), cur_stream()), 100, use_graph=g)
-        rec(f"mmq_{names[t]}_batch8", us, algo_bytes_matmul(t, N_DIM, K_DIM, 8), 2.0 * 8 * N_DIM * K_DIM)
-    us, _ = time_launches(lambda: L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 200, use_graph=g)
-    res["quantize_mmq_q8_1_batch128"] = {"us": round(us, 3)}
-    us, _ = time_launches(lambda: L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 200, use_graph=g)
-    res["quantize_q8_1_tiled_batch128"] = {"us": round(us, 3)}
-    # BASELINE configs[4]: the per-rank shard of Q4_K 8192 x 28672 over 8 GPUs = 3584 rows x K 8192, batch 1 / 8 / 128
-    K5, N5 = 8192, 3584
-    w5 = torch.from_numpy(synth.random_weight(Q4_K, N5, K5, seed=5)).to(dev)
-    x5 = torch.randn((BATCH, K5), generator=torch.Generator().manual_seed(5)).half().to(dev)
-    y5 = torch.empty((BATCH, N5), dtype=torch.float16, device=dev)
-    sc5 = torch.empty(int(L.ggq_mmq_scratch_bytes(BATCH, K5)), dtype=torch.uint8, device=dev)
-    for b in (8, BATCH):
-        xb = x5[:b].contiguous()
-        us, _ = time_launches(lambda: L.ggq_mul_mat_q(vp(w5), vp(xb), vp(y5), Q4_K, 1, b, K5, N5, vp(sc5), cur_stream()), 100, use_graph=g)
-        rec(f"mmq_Q4_K_shard_3584x8192_batch{b}", us, algo_bytes_matmul(Q4_K, N5, K5, b), 2.0 * b * N5 * K5)
-    x51 = x5[:1].contiguous()
-    us, _ = time_launches(lambda: L.ggq_mul_mat_vec_q(vp(w5), vp(x51), vp(y5), Q4_K, 1, K5, N5, vp(sc5), cur_stream()), 200, use_graph=g)
-    rec("mmvq_Q4_K_shard_3584x8192_batch1", us, algo_bytes_matmul(Q4_K, N5, K5, 1), 2.0 * N5 * K5)
+        rec(f"mmq_{NAMES[t]}_batch8",
+            lambda b, t=t: L.ggq_mul_mat_q(vp(b[0]), vp(x8), vp(y128), t, 1, 8, K_DIM, N_DIM, vp(scratch), cur_stream()),
+            [rings[t]], algo_bytes_matmul(t, N_DIM, K_DIM, 8), 2.0 * 8 * N_DIM * K_DIM)
+    st = time_launches(lambda i: L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 208, use_graph=g)
+    res["quantize_mmq_q8_1_batch128"] = dict(st, cache_state="warm: 1 MB of activations, 0.7 MB of scratch")
+    st = time_launches(lambda i: L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 208, use_graph=g)
+    res["quantize_q8_1_tiled_batch128"] = dict(st, cache_state="warm: 1 MB of activations, 0.7 MB of scratch")
     # FFN gate + up on one activation quantisation (ggq.linear): quantise once, two streamed matmuls
-    def gate_up():
+    def gate_up(b):
         L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
-        L.ggq_mul_mat_q_pretiled(vp(w_q4k), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
-        L.ggq_mul_mat_q_pretiled(vp(ws[Q5_K]), vp(scratch), vp(y128), Q5_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
-    us, _ = time_launches(gate_up, 100, use_graph=g)
-    res["gate_up_Q4_K_Q5_K_batch128_shared_quantisation"] = {"us": round(us, 3), "note": "two separate ggml_mul_mat_a8 calls: mmq_Q4_K + mmq_Q5_K step times"}
-    # the reference-layout kernel (other formats' path) on the headline shape, for comparison
-    L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
-    us, _ = time_launches(lambda: L.ggq_mul_mat_q_prequant(vp(w_q4k), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream()), 100, use_graph=g)
-    rec("mmq_Q4_K_batch128_lds_tile_kernel_only", us, algo_bytes_matmul(Q4_K, N_DIM, K_DIM, BATCH), 2.0 * BATCH * N_DIM * K_DIM)
+        L.ggq_mul_mat_q_pretiled(vp(b[0]), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+        L.ggq_mul_mat_q_pretiled(vp(b[1]), vp(scratch), vp(y128), Q5_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+    rec("gate_up_Q4_K_Q5_K_batch128_shared_quantisation", gate_up, [rings[Q4_K], rings[Q5_K]],
+        algo_bytes_matmul(Q4_K, N_DIM, K_DIM, BATCH) + algo_bytes_matmul(Q5_K, N_DIM, K_DIM, BATCH), 4.0 * BATCH * N_DIM * K_DIM)
+    res["gate_up_Q4_K_Q5_K_batch128_shared_quantisation"]["note"] = "compare with the two separate ops: step time + mmq_Q5_K_batch128"
     return res
 
 

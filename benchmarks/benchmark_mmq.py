@@ -6,6 +6,11 @@ synchronised loop), same CLI.  Differences forced by the environment: the sample
 with synthetic block-valid tensors (ggq.gguf_io) instead of snapshot_download("Isotr0py/test-gguf-sample"),
 gguf.GGUFReader is ours, and --hidden-size / --rows accept any size (the hub samples exist for 256 / 1024
 only).  Adds a kernel-only column (HIP events around a hipGraph of the op) and algorithmic GB/s.
+Like the reference it writes `benchmark_results_local_HD{hidden}xB{tokens}.csv` with the columns
+`Quantization, Dequant Time (ms), MMQ Time (ms)` (benchmark_mmq.py:177, 195-197; extra columns appended) and
+`--profile` brackets ONE iteration of each column with the profiler start/stop calls plus a named range
+(benchmark_mmq.py:76-77, 92-93: cudaProfilerStart/Stop -> hipProfilerStart/Stop on ROCm; the range shows up as a
+roctx marker in rocprofv3 --marker-trace) after `--num-warmup-iters`, instead of the timed loop.
 
   python benchmarks/benchmark_mmq.py --quant-dtype Q4_K --hidden-size 4096 --rows 11008 --num-tokens 128
   python benchmarks/benchmark_mmq.py --all --num-tokens 1 8 128
@@ -69,8 +74,27 @@ def kernel_time_us(fn, iters=50):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+class profiled:
+    """the reference's `--profile` bracket (benchmark_mmq.py:76-77, 92-93) + a named range"""
+
+    def __init__(self, name, on):
+        self.name, self.on = name, on
+
+    def __enter__(self):
+        if self.on:
+            torch.cuda.synchronize()
+            torch.cuda.cudart().cudaProfilerStart()
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *a):
+        if self.on:
+            torch.cuda.synchronize()
+            torch.cuda.nvtx.range_pop()
+            torch.cuda.cudart().cudaProfilerStop()
+
+
 @torch.inference_mode()
-def main(num_tokens, hidden_size, quant_type, dtype, rows, sample_dir, seed=0, num_warmup_iters=5, num_iters=100):
+def main(num_tokens, hidden_size, quant_type, dtype, rows, sample_dir, seed=0, num_warmup_iters=5, num_iters=100, profile=False):
     import ggml as ops
     seed_everything(seed)
     x = torch.randn(num_tokens, hidden_size, dtype=dtype, device="cuda")
@@ -99,9 +123,17 @@ def main(num_tokens, hidden_size, quant_type, dtype, rows, sample_dir, seed=0, n
         return (time.perf_counter() - t0) / n
 
     run_dequant(num_warmup_iters)
-    dequant_ms = run_dequant(num_iters) * 1e3
+    if profile:
+        with profiled(f"dequant+matmul {quant_type.name}", True):
+            dequant_ms = run_dequant(1) * 1e3
+    else:
+        dequant_ms = run_dequant(num_iters) * 1e3
     run_mmq(num_warmup_iters)
-    mmq_ms = run_mmq(num_iters) * 1e3
+    if profile:
+        with profiled(f"ggml_mul_mat_a8 {quant_type.name}", True):
+            mmq_ms = run_mmq(1) * 1e3
+    else:
+        mmq_ms = run_mmq(num_iters) * 1e3
     kern_us = sum(kernel_time_us(lambda t=t: matmul(t, x, quant_type, t.size(0))) for t in w)
     esz = x.element_size()
     nbytes = sum(m * row_bytes(quant_type, n) + num_tokens * n * esz + num_tokens * m * esz for m, n in shape)
@@ -121,10 +153,23 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", type=str, choices=DTYPES_MAP.keys(), default="half")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--sample-dir", type=str, default=None, help="where Quant_{TYPE}_{hidden}.gguf are kept (default: a temp dir)")
+    ap.add_argument("--profile", action="store_true", help="profile one iteration of each column instead of timing the loop")
+    ap.add_argument("--num-warmup-iters", type=int, default=5)
+    ap.add_argument("--num-iters", type=int, default=100)
+    ap.add_argument("--csv-dir", type=str, default=".", help="where benchmark_results_local_HD{hidden}xB{tokens}.csv is written")
     args = ap.parse_args()
     sample_dir = args.sample_dir or tempfile.mkdtemp(prefix="ggq_gguf_samples_")
     os.makedirs(sample_dir, exist_ok=True)
     types = list(QUANT_TYPES_MAP.values()) if args.all else [QUANT_TYPES_MAP[args.quant_dtype]]
-    for qt in types:
-        for nt in args.num_tokens:
-            print(json.dumps(main(nt, args.hidden_size, qt, DTYPES_MAP[args.dtype], args.rows, sample_dir, seed=args.seed)), flush=True)
+    import pandas as pd
+    for nt in args.num_tokens:
+        rows_out = []
+        for qt in types:
+            r = main(nt, args.hidden_size, qt, DTYPES_MAP[args.dtype], args.rows, sample_dir, seed=args.seed,
+                     num_warmup_iters=args.num_warmup_iters, num_iters=args.num_iters, profile=args.profile)
+            print(json.dumps(r), flush=True)
+            rows_out.append({"Quantization": r["quant"], "Dequant Time (ms)": r["dequant_path_ms"], "MMQ Time (ms)": r["mmq_path_ms"],
+                             "MMQ kernels (us)": r["mmq_kernels_us"], "Algorithmic GB/s": r["algorithmic_GBps"]})
+        # the reference's result file (benchmark_mmq.py:177, 195-197), one per (hidden size, token count)
+        os.makedirs(args.csv_dir, exist_ok=True)
+        pd.DataFrame(rows_out).to_csv(os.path.join(args.csv_dir, f"benchmark_results_local_HD{args.hidden_size}xB{nt}.csv"), index=False)

@@ -16,6 +16,11 @@
 //     by the 4-32 neighbouring lanes of the same block and served by one L1 line);
 //     a wave's loads cover a contiguous byte range of the weight row;
 //   * no LDS: nothing is reused across lanes except the block header.
+// Measured round 2 (scripts/sweep_dequant.py, 11008 x 4096): with the tensor resident in L2 + Infinity Cache ("warm")
+// Q4_K runs at 70-72 % of the 8 TB/s roof; streamed from HBM with 4 distinct 90 MB outputs ("cold") at 49 %, Q8_0 at
+// 66 %.  On the same box a plain device copy of 86 MB reaches 5.1 TB/s (64 %) cold and a fill 6.2 TB/s.  Tried for
+// the cold case without gain: nontemporal stores (+-0), two chunks per thread (Q4_K 49 -> 40 %), a grid-stride
+// loop that touches the next chunk's bytes one iteration ahead (45 %).
 #include "ggq_common.h"
 
 #ifndef GGQ_DEQUANT_CH
@@ -245,6 +250,7 @@ static int launch_dequant(const void* w, void* out, int64_t k, hipStream_t s) {
   const int64_t n_threads = n_chunks / CH;   // QK / 8 is 4 or 32: divisible by CH
   const int64_t grid = (n_threads + 255) / 256;
   if (grid > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL((dequant_kernel<T, CH>), dim3((unsigned)grid), dim3(256), 0, s,
                      (const uint8_t*)w, (_Float16*)out, n_chunks);
   GGQ_HIP_CHECK_LAUNCH();

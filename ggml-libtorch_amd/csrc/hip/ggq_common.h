@@ -135,10 +135,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// GGQ_HIP_PRE_LAUNCH() before a launch drops a sticky error some earlier, unrelated HIP call left behind, so that
+// GGQ_HIP_CHECK_LAUNCH() after it reports this launch only.
+#define GGQ_HIP_PRE_LAUNCH() ((void)hipGetLastError())
 #define GGQ_HIP_CHECK_LAUNCH()                          \
   do {                                                  \
     hipError_t e_ = hipGetLastError();                  \
     if (e_ != hipSuccess) return GGQ_ERR_LAUNCH;        \
   } while (0)
+
+// Experiment knobs (environment variables that force a kernel variant) exist only in -DGGQ_TUNING builds
+// (scripts/build_variant.sh); the shipped library takes no decision from the environment.
+#ifdef GGQ_TUNING
+#define GGQ_TUNING_ENV(name) getenv(name)
+#else
+#define GGQ_TUNING_ENV(name) ((const char*)nullptr)
+#endif
 
 }  // namespace ggq

@@ -317,15 +317,14 @@ static int launch_mmq_cfg(const void* w, const void* q8, void* y, int64_t batch,
                           int64_t ldy, hipStream_t s) {
   using L = MmqLds<T, TBn>;
   auto kern = mmq_kernel<T, DT, TBn>;
-  static bool attr_set = false;  // one-time per instantiation (the reference does it on every call)
-  if (L::BYTES > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES) != hipSuccess)
-      return GGQ_ERR_LAUNCH;
-    attr_set = true;
-  }
+  // per call, like the reference (mmq.cuh:2022): the attribute is per device, and the op may run on any of them
+  if (L::BYTES > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES) != hipSuccess)
+    return GGQ_ERR_LAUNCH;
   const int64_t n_tok_tiles = (batch + L::TT - 1) / L::TT;
   const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
   if (n_units > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)n_units), dim3(512), L::BYTES, s, (const uint8_t*)w,
                      (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy, (int)n_tok_tiles);
   GGQ_HIP_CHECK_LAUNCH();
@@ -481,6 +480,7 @@ static int launch_mmq_small_n(const void* w, const void* q8, void* y, int64_t ba
   rpw = rpw < 1 ? 1 : rpw;
   const int64_t waves = (n + rpw - 1) / rpw;
   const int64_t grid = (waves + 15) / 16;
+  GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, (const uint8_t*)w, (const uint8_t*)q8, y,
                      (int)k, (int)n, (int)batch, ldy, rpw);
   GGQ_HIP_CHECK_LAUNCH();
@@ -499,7 +499,7 @@ template <int T, int DT>
 static int launch_mmq_t(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
                         int64_t ldy, hipStream_t s) {
   if (batch <= 8) {  // HBM-bound regime: stream the weights once, dot4 against every token
-    static const char* e = getenv("GGQ_MMQ_SMALL");
+    static const char* e = GGQ_TUNING_ENV("GGQ_MMQ_SMALL");
     if (!e || e[0] != '0') {
       const int rc = launch_mmq_small<T, DT>(w, q8, y, batch, k, n, ldy, s);
       if (rc != -100) return rc;
@@ -751,9 +751,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 #endif
 
   for (int p = p_begin; p < p_end; ++p) {
-#ifdef GGQ_MAGIC_RESIDENT
-    asm volatile("" : "+v"(magic));   // keep the accumulator preset in registers instead of re-creating it from SGPRs every pair
-#endif
+    asm volatile("" : "+v"(magic));   // keep the accumulator preset in registers: hipcc otherwise re-creates it from SGPRs every pair (-2 %)
     const int st = p / IPS, q = p % IPS;
     // abase[] points at pair p; step to the next pair (the last iteration re-reads its own pair)
     const bool more = p + 1 < p_end;
@@ -1053,13 +1051,11 @@ static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t 
   constexpr int LDS = StreamLaunch<T, TB, KS>::LDS;
   auto kern = mmq_stream_kernel<T, DT, TB, KS, NR>;
   if (LDS > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
-      attr_set = true;
-    }
+    // per call: the attribute is per device (a process may drive several GPUs), and it is a cheap host call
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
   }
   const int64_t per_xcd = (n_units + 7) / 8;
+  GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(64 * KS), LDS, s,
                      (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy,
                      (int)n_tok_tiles, (int)n_units, (int)per_xcd);
@@ -1078,12 +1074,12 @@ static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t bat
   //   shapes, 4096 rows x 128 tokens = 256 units: 40.1 -> 32.5 us; with 344 units it would need a second round);
   //   32-token units (<= 128 VGPRs, two workgroups per CU): up to 512 units — the batch <= 32 case of the 11008-row
   //   shape is otherwise a latency chain of 16 pair-iterations per wave at 1.3 waves per SIMD.
-  static const char* e = getenv("GGQ_MMQ_KS");
+  static const char* e = GGQ_TUNING_ENV("GGQ_MMQ_KS");
   const int64_t n_st = (k + StreamCfg<T>::SE - 1) / StreamCfg<T>::SE;
   const bool two_per_cu = StreamLaunch<T, TB, 8>::WG_PER_CU == 2;
   const bool ks8 = e ? e[0] == '8' : (n_units <= (two_per_cu ? 512 : 256) && n_st >= 16);
   if constexpr (TB == 1) {   // batch <= 16: transposed variant, only the registers that hold tokens are scaled
-    static const char* et = getenv("GGQ_MMQ_TRANS");
+    static const char* et = GGQ_TUNING_ENV("GGQ_MMQ_TRANS");
     const bool trans = et ? et[0] == '1' : true;
     if (trans && batch <= 8)
       return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s)
@@ -1103,7 +1099,7 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
                             int64_t n, int64_t ldy, hipStream_t s) {
   // 32-token units while one token tile covers the batch, 64-token units beyond (measured r1, Q4_K
   // 11008x4096: batch 32 14.4 vs 20.0 us, batch 128 38.8 vs 29.9 us)
-  static const char* e = getenv("GGQ_MMQ_TB");   // experiments: force 32- or 64-token units
+  static const char* e = GGQ_TUNING_ENV("GGQ_MMQ_TB");   // experiments: force 32- or 64-token units
   // (Q2_K's second int8 tile does not fit 168 VGPRs with two token blocks: 168 us spilled vs 54 us)
   const bool one = e ? e[0] == '1' : (batch <= 32 || MmqTraits<T>::two_tiles);
   switch (dt) {

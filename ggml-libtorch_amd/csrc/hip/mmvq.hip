@@ -427,6 +427,7 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GGQ_ERR_LAUNCH;
   }
+  GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FUSED ? 1024 : 256), lds, s, (const uint8_t*)w,
                      (const uint8_t*)q8, y, (int)k, (int)n, rpw);
   GGQ_HIP_CHECK_LAUNCH();
@@ -488,7 +489,7 @@ extern "C" int ggq_mul_mat_vec_q(const void* w, const void* x, void* y, int type
   if (n_rows == 0) return GGQ_OK;
   if (!w || !x || !y) return GGQ_ERR_ARG;
   if ((uintptr_t)w & 1) return GGQ_ERR_ALIGN;
-  static const char* e = getenv("GGQ_MMVQ_FUSED");   // 0: two launches (quantize_q8_1 + mul_mat_vec_q), for comparison
+  static const char* e = GGQ_TUNING_ENV("GGQ_MMVQ_FUSED");   // 0: two launches (quantize_q8_1 + mul_mat_vec_q), for comparison
   if (e && e[0] == '0') {
     const int rc = ggq_quantize_q8_1(x, dtype, scratch, 1, k, stream);
     if (rc != GGQ_OK) return rc;

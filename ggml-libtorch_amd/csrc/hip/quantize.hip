@@ -114,12 +114,15 @@ static int launch_quant(const void* x, int dt, void* q, int64_t batch, int64_t k
     uint8_t* qo = (uint8_t*)q;
     switch (dt) {
       case GGQ_F32:
+        GGQ_HIP_PRE_LAUNCH();
         hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F32, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
         break;
       case GGQ_F16:
+        GGQ_HIP_PRE_LAUNCH();
         hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
         break;
       case GGQ_BF16:
+        GGQ_HIP_PRE_LAUNCH();
         hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_BF16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
         break;
       default: return GGQ_ERR_DTYPE;

@@ -62,6 +62,39 @@ def gather_slabs(y_local: torch.Tensor, n_rows: int, group=None, out: Optional[t
     return torch.cat(parts, dim=1), None
 
 
+class SlabGather:
+    """Gather without a staging copy: a preallocated [P, batch, rows] buffer whose slot r is rank r's output slab.
+
+    The rank's matmul writes its [batch, rows] slab straight into `local` (a contiguous view of slot `rank`:
+    `ggq_mul_mat_q_ld` / the torch op with `out=`), and `gather()` all-gathers IN PLACE — the collective's input is
+    the rank's own slot of its output (the in-place form of ncclAllGather), so no slab is copied locally and no
+    second buffer exists.  Consumers that want [batch, N] take `batch_major()` (one permute copy) or, better,
+    consume the [P, batch, rows] form directly (a following row-parallel layer reads it shard by shard).
+    Equal shards only (n_rows % P == 0): ragged splits go through `gather_slabs`."""
+
+    def __init__(self, batch: int, n_rows: int, dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if n_rows % self.world:
+            raise ValueError("SlabGather needs equal shards (n_rows % world_size == 0)")
+        self.batch, self.rows = batch, n_rows // self.world
+        self.buf = torch.empty((self.world, batch, self.rows), dtype=dtype, device=device)
+
+    @property
+    def local(self) -> torch.Tensor:
+        return self.buf[self.rank]
+
+    def gather(self, async_op: bool = False):
+        if self.world == 1:
+            return None
+        return dist.all_gather_into_tensor(self.buf.view(self.world * self.batch, self.rows), self.local, group=self.group,
+                                           async_op=async_op)
+
+    def batch_major(self) -> torch.Tensor:
+        return unpermute_gathered(self.buf)
+
+
 def unpermute_gathered(buf: torch.Tensor) -> torch.Tensor:
     """[P, batch, rows] gather buffer -> [batch, P*rows]"""
     p, b, r = buf.shape

@@ -134,9 +134,10 @@ int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int type, int 
 /* Fragment-major variant of the MMQ activation scratch (same 144 bytes per 128 elements and token,
  * same values as ggq_quantize_q8_1_mmq, regrouped per (k/128, token/32) into 4608-byte tiles
  * { int8 qs[4 groups][2 K-halves][32 tokens][16]; ds[2 group pairs][32 tokens][2] } so that one MFMA
- * operand fragment is 1 KB contiguous).  This is what ggq_mul_mat_q uses internally for the formats
- * ggq_mmq_tiled_supported() reports (Q4_K / Q5_K with k % 256 == 0); exported so a caller can quantise
- * once for several weight matrices (as the reference does per layer, HK/ggml/mmq.cu:208-230).
+ * operand fragment is 1 KB contiguous).  This is what ggq_mul_mat_q uses internally from batch 5 (33 for
+ * Q6_K, 65 for Q8_0) for every (type, k) ggq_mmq_tiled_supported() reports: all ten formats, k a whole
+ * number of blocks, rows of at most 32 MiB; exported so a caller can quantise once for several weight
+ * matrices (the reference quantises per call, HK/ggml/mmq.cu:208-230).
  * q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte aligned.  w must be 16-byte aligned. */
 int ggq_mmq_tiled_supported(int type, int64_t k);
 int ggq_quantize_q8_1_tiled(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from ggq import synth
-from ggq.dist import shard_rows, gather_slabs, unpermute_gathered, RowShardedQuantLinear
+from ggq.dist import shard_rows, gather_slabs, unpermute_gathered, RowShardedQuantLinear, SlabGather
 from ggq.formats import GGMLType
 
 
@@ -59,6 +59,16 @@ def _worker(rank, world, port, n_rows, quant_type, tmp):
             buf, work = gather_slabs(layer.local(x), n_rows, async_op=True)
             work.wait()
             assert np.array_equal(unpermute_gathered(buf).numpy(), ref)
+            # in-place form (bench.py's configs[4] leg): the slab is written into the rank's slot, gathered in place
+            sg = SlabGather(batch, n_rows, torch.float32, "cpu")
+            sg.local.copy_(layer.local(x))          # on the GPU the kernel writes here directly (row pitch = rows)
+            before = sg.local.data_ptr()
+            sg.gather()
+            assert sg.local.data_ptr() == before and sg.buf.shape == (world, batch, n_rows // world)
+            assert np.array_equal(sg.batch_major().numpy(), ref)
+            for r in range(world):                  # slot r = rank r's columns, untouched layout
+                s_r, e_r = shard_rows(n_rows, world, r)
+                assert np.array_equal(sg.buf[r].numpy(), ref[:, s_r:e_r])
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -37,6 +37,23 @@ def test_dequantize_bit_exact(oracle, t):
     assert util.same_nan(got, ref), f"{t.name}: fp16 bit patterns differ from the oracle"
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q5_0, GGMLType.Q8_0], ids=lambda t: t.name)
+def test_dequantize_vs_reference_golden(t):
+    """The HIP kernel against output the REFERENCE itself produced (no oracle in between): the blocks of
+    tests/golden/reference_cpu_dequant.npz were decoded by the reference's compiled ggml-cpu op
+    (ggml-cpu/ggml-quants.hpp:4-112, fp32).  For these three formats the GPU result `__hmul(d, q)`
+    (HK/ggml/dequantize.cuh:3-78) is one IEEE rounding of the exact product d·q, and so is fp16(reference fp32):
+    the fp32 product of an 11-bit and an at most 8-bit significand is exact.  (Q4_1 / Q5_1 round twice on the GPU,
+    hmul then hadd, and are compared with the oracle only.)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_cpu_dequant.npz"))
+    blocks, bits = g[f"{t.name}_blocks"], g[f"{t.name}_f32_bits"]
+    with np.errstate(over="ignore"):
+        want = bits.view(np.float32).astype(np.float16)   # round-to-nearest-even; overflow -> inf, NaN stays NaN
+    got = util.gpu_dequant(blocks, t, 1, blocks.shape[0] * 32).reshape(-1)
+    assert util.same_nan(got, want), f"{t.name}: HIP fp16 != RN_fp16(reference ggml-cpu fp32)"
+
+
 @pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
 def test_dequantize_ragged_and_tiny(oracle, t):
     qk, _ = BLOCK[t]
@@ -239,7 +256,7 @@ def test_mmq_integer_exact(oracle):
         assert np.array_equal(y, ref), f"{t.name}: exact-integer MMQ differs"
 
 
-@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q6_K, GGMLType.Q8_0], ids=lambda t: t.name)
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K, GGMLType.Q8_0], ids=lambda t: t.name)
 def test_mmq_full_size_rows_sample(oracle, t):
     """BASELINE config 4 shape (K=4096, N=11008, batch 128): oracle on a sample of rows +
     the row-permutation property (permuting W's rows permutes Y's columns bit-exactly)."""

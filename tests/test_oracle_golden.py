@@ -30,6 +30,20 @@ def test_oracle_matches_reference_cpu_golden(oracle, t):
     assert np.array_equal(y.view(np.uint32), bits), "oracle fp32 dequantise != reference ggml-cpu op (bit patterns)"
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q5_0, GGMLType.Q8_0], ids=lambda t: t.name)
+def test_oracle_fp16_path_is_one_rounding_of_the_reference_fp32(oracle, t):
+    """the oracle's fp16 (GPU-semantics) dequantise of Q4_0 / Q5_0 / Q8_0 == RN_fp16(reference fp32 golden):
+    pins the fp16 path of these formats to reference-held output (same argument as the -m gpu twin in
+    tests/test_gpu_parity.py::test_dequantize_vs_reference_golden)."""
+    g = np.load(os.path.join(GOLD, "reference_cpu_dequant.npz"))
+    blocks, bits = g[f"{t.name}_blocks"], g[f"{t.name}_f32_bits"]
+    with np.errstate(over="ignore"):
+        want = bits.view(np.float32).astype(np.float16)
+    got = oracle.dequantize_f16(blocks, t, blocks.shape[0] * 32)
+    an, bn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(an, bn) and np.array_equal(got.view(np.uint16)[~an], want.view(np.uint16)[~bn])
+
+
 @pytest.mark.parametrize("t", LEGACY, ids=lambda t: t.name)
 def test_oracle_matches_live_reference_when_present(oracle, t):
     ref = oracle.load_reference_cpu_op()
