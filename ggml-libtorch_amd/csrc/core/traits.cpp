@@ -21,10 +21,10 @@ extern "C" const char* ggq_strerror(int status) {
 extern "C" int ggq_block_elems(int type) {
   switch (type) {
     case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: case GGQ_TYPE_Q5_1:
-    case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1:
+    case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: case GGQ_TYPE_IQ4_NL:
       return 32;
     case GGQ_TYPE_Q2_K: case GGQ_TYPE_Q3_K: case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K:
-    case GGQ_TYPE_Q6_K:
+    case GGQ_TYPE_Q6_K: case GGQ_TYPE_IQ4_XS:
       return 256;
     default: return 0;
   }
@@ -43,6 +43,8 @@ extern "C" int ggq_block_bytes(int type) {
     case GGQ_TYPE_Q4_K: return 144;
     case GGQ_TYPE_Q5_K: return 176;
     case GGQ_TYPE_Q6_K: return 210;
+    case GGQ_TYPE_IQ4_NL: return 18;    // block_iq4_nl, HK/ggml/ggml-common.h:176-182
+    case GGQ_TYPE_IQ4_XS: return 136;   // block_iq4_xs, HK/ggml/ggml-common.h:184-191
     default: return 0;
   }
 }
@@ -56,6 +58,11 @@ extern "C" int64_t ggq_row_bytes(int type, int64_t k) {
 
 extern "C" int ggq_type_supported(int type) {
   return type != GGQ_TYPE_Q8_1 && ggq_block_elems(type) != 0;
+}
+
+// the ten cases of ggml_mul_mat_a8's switch (HK/ggml/mmq.cu:222-251): no IQ format
+extern "C" int ggq_mmq_type_supported(int type) {
+  return ggq_type_supported(type) && type != GGQ_TYPE_IQ4_NL && type != GGQ_TYPE_IQ4_XS;
 }
 
 // mmq_need_sum, HK/ggml/mmq.cu:84-106

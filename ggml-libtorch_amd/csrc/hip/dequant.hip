@@ -220,6 +220,39 @@ template <> struct Decode<GGQ_TYPE_Q6_K> {
   }
 };
 
+// IQ4_NL / IQ4_XS (HK/ggml/dequantize.cuh:399-433): fp32 arithmetic — d (x (ls - 32)) x codebook value — and ONE
+// rounding to fp16 (`__float2half`), unlike the fp16 sequences above.  Chunk `sub` holds elements 8 sub..8 sub + 7
+// of a 32-element (sub-)block: low nibbles of qs[0..15] are elements 0..15, high nibbles elements 16..31.
+__device__ __forceinline__ void iq4_chunk(const uint8_t* qs16, int sub4, float d, _Float16* y) {
+  const u32x2_a2 q = ld_u32x2(qs16 + 8 * (sub4 & 1));
+  const int sh = 4 * (sub4 >> 1);
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const uint32_t v4 = iq4nl_lookup4((q.v[w] >> sh) & 0x0F0F0F0Fu);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float p = d * (float)(int8_t)(v4 >> (8 * e));
+      // keep the product a plain v_mul_f32: folded with the conversion hipcc emits v_fma_mix*_f16 p = d·v + (+0),
+      // which turns the reference's -0 (d = 0 or ls = 32 times a negative codebook value) into +0
+      asm volatile("" : "+v"(p));
+      y[4 * w + e] = (_Float16)p;
+    }
+  }
+}
+template <> struct Decode<GGQ_TYPE_IQ4_NL> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    iq4_chunk(b + off::IQ4_NL_QS, sub, bits_h_f32(ld_u16(b + off::IQ4_NL_D)), y);
+  }
+};
+template <> struct Decode<GGQ_TYPE_IQ4_XS> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int ib = sub >> 2;   // 32-element sub-block
+    const u32x2_a2 hd = ld_u32x2(b);   // {d | scales_h << 16, scales_l}
+    const float d = bits_h_f32(hd.v[0] & 0xFFFF) * (float)iq4xs_scale(hd.v[0] >> 16, hd.v[1], ib);
+    iq4_chunk(b + off::IQ4_XS_QS + 16 * ib, sub & 3, d, y);
+  }
+};
+
 // CH = consecutive 8-element chunks per thread (1 or 2).  Two chunks of the same 16-element run share the block
 // header loads and the sub-scale decode (the compiler merges them), which is what bounded Q3_K / Q6_K.
 template <int T, int CH>
@@ -282,6 +315,8 @@ extern "C" int ggq_dequantize_f16(const void* w, void* out, int type, int64_t m,
     case GGQ_TYPE_Q4_K: return launch_dequant<GGQ_TYPE_Q4_K>(w, out, k, s);
     case GGQ_TYPE_Q5_K: return launch_dequant<GGQ_TYPE_Q5_K>(w, out, k, s);
     case GGQ_TYPE_Q6_K: return launch_dequant<GGQ_TYPE_Q6_K>(w, out, k, s);
+    case GGQ_TYPE_IQ4_NL: return launch_dequant<GGQ_TYPE_IQ4_NL>(w, out, k, s);
+    case GGQ_TYPE_IQ4_XS: return launch_dequant<GGQ_TYPE_IQ4_XS>(w, out, k, s);
     default: return GGQ_ERR_TYPE;
   }
 }

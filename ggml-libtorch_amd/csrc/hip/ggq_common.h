@@ -60,6 +60,8 @@ GGQ_FMT(GGQ_TYPE_Q3_K, 256, 110)
 GGQ_FMT(GGQ_TYPE_Q4_K, 256, 144)
 GGQ_FMT(GGQ_TYPE_Q5_K, 256, 176)
 GGQ_FMT(GGQ_TYPE_Q6_K, 256, 210)
+GGQ_FMT(GGQ_TYPE_IQ4_NL, 32, 18)
+GGQ_FMT(GGQ_TYPE_IQ4_XS, 256, 136)
 #undef GGQ_FMT
 
 // byte offsets inside a block (HK/ggml/ggml-common.h:20-108)
@@ -74,7 +76,26 @@ constexpr int Q3_K_HM = 0, Q3_K_QS = 32, Q3_K_SC = 96, Q3_K_D = 108;
 constexpr int Q4_K_D = 0, Q4_K_DMIN = 2, Q4_K_SC = 4, Q4_K_QS = 16;
 constexpr int Q5_K_D = 0, Q5_K_DMIN = 2, Q5_K_SC = 4, Q5_K_QH = 16, Q5_K_QS = 48;
 constexpr int Q6_K_QL = 0, Q6_K_QH = 128, Q6_K_SC = 192, Q6_K_D = 208;
+constexpr int IQ4_NL_D = 0, IQ4_NL_QS = 2;                                // HK/ggml/ggml-common.h:179-182
+constexpr int IQ4_XS_D = 0, IQ4_XS_SH = 2, IQ4_XS_SL = 4, IQ4_XS_QS = 8;   // HK/ggml/ggml-common.h:186-191
 }  // namespace off
+
+// kvalues_iq4nl (HK/ggml/ggml-common.h:1060), the 16-entry non-linear 4-bit codebook, as four little-endian dwords:
+// {-127,-104,-83,-65, -49,-35,-22,-10, 1,13,25,38, 53,69,89,113}.  Four nibbles (one per byte of `idx4`, 0..15) are
+// looked up at once with two v_perm_b32 (an 8-byte table half each) and a per-byte select on bit 3 — the job of
+// get_int_from_table_16 (HK/ggml/vecdotq.cuh:828-840) without its sixteen byte loads.
+__device__ __forceinline__ uint32_t iq4nl_lookup4(uint32_t idx4) {
+  constexpr uint32_t T0 = 0xBFAD9881u, T1 = 0xF6EADDCFu, T2 = 0x26190D01u, T3 = 0x71594535u;
+  const uint32_t sel = idx4 & 0x07070707u;
+  const uint32_t lo = __builtin_amdgcn_perm(T1, T0, sel);   // entries 0..7
+  const uint32_t hi = __builtin_amdgcn_perm(T3, T2, sel);   // entries 8..15
+  const uint32_t m = ((idx4 >> 3) & 0x01010101u) * 0xFFu;   // 0xFF in the bytes whose index has bit 3 set
+  return (lo & ~m) | (hi & m);
+}
+// the 6-bit scale of 32-element sub-block ib of an IQ4_XS super-block (dequantize.cuh:428, vecdotq.cuh:876), minus 32
+__device__ __forceinline__ int iq4xs_scale(uint32_t scales_h, uint32_t scales_l, int ib) {
+  return (int)(((scales_l >> (4 * ib)) & 0xF) | (((scales_h >> (2 * ib)) & 3) << 4)) - 32;
+}
 
 // 6-bit (scale, min) pair j of the 12-byte Q4_K/Q5_K scale field, from the three
 // little-endian dwords s0,s1,s2 of that field (layout: HK/ggml/dequantize.cuh:154-161).

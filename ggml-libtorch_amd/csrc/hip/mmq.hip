@@ -533,7 +533,7 @@ extern "C" int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int
                                       void* stream) {
   using namespace ggq;
   if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
-  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
   if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
   if (k > (1 << 30) || n_rows > 0x7fffffffLL - 64 || batch > 0x7fffffffLL / 256) return GGQ_ERR_SHAPE;
   if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
@@ -1114,7 +1114,7 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
 extern "C" int ggq_mmq_tiled_supported(int type, int64_t k) {
   // the streamed kernel addresses a 32-row weight tile with 32-bit byte offsets: rows up to 32 MiB (K of a few
   // tens of millions); longer rows stay on the reference-layout kernel
-  return ggq_type_supported(type) && k > 0 && k % ggq_block_elems(type) == 0 && ggq_row_bytes(type, k) <= (32 << 20);
+  return ggq_mmq_type_supported(type) && k > 0 && k % ggq_block_elems(type) == 0 && ggq_row_bytes(type, k) <= (32 << 20);
 }
 
 extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int type, int dtype,
@@ -1122,7 +1122,7 @@ extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int
                                       void* stream) {
   using namespace ggq;
   if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
-  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
   if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
   if (!ggq_mmq_tiled_supported(type, k)) return GGQ_ERR_TYPE;
   if (k > (1 << 30) || n_rows > 0x7fffffffLL - 64 || batch > 0x7fffffffLL / 256) return GGQ_ERR_SHAPE;

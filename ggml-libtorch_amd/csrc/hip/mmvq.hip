@@ -277,6 +277,37 @@ template <> struct UnitDot<GGQ_TYPE_Q6_K> {  // vecdotq.cuh:327-345, 587-605
   }
 };
 
+// IQ4_NL / IQ4_XS (vecdotq.cuh:842-888): the nibbles index the 16-entry int8 codebook; unit = the 16 quant bytes
+// of one 32-element (sub-)block: low nibbles x q8[0..15], high nibbles x q8[16..31]; float part d · (ls - 32) · d8.
+template <> struct UnitDot<GGQ_TYPE_IQ4_NL> {
+  static constexpr int UPB = 1;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)u * 18;
+    const u32x4_a2 q = ld_u32x4(b + off::IQ4_NL_QS);
+    const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = iq4nl_lookup4(q.v[i] & 0x0F0F0F0F); hi[i] = iq4nl_lookup4((q.v[i] >> 4) & 0x0F0F0F0F); }
+    const float d = bits_h_f32(ld_u16(b)) * A.xd[u];
+    return d * (float)(dot16(lo, a0) + dot16(hi, a1));
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_IQ4_XS> {
+  static constexpr int UPB = 8;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const int ib = u >> 3, ib32 = u & 7, g = u;   // group g = 8 ib + ib32
+    const uint8_t* b = row + (int64_t)ib * 136;
+    const u32x2_a2 hd = ld_u32x2(b);
+    const u32x4_a2 q = ld_u32x4(b + off::IQ4_XS_QS + 16 * ib32);
+    const v4i a0 = lds_ld16(A.xq + 32 * g), a1 = lds_ld16(A.xq + 32 * g + 16);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = iq4nl_lookup4(q.v[i] & 0x0F0F0F0F); hi[i] = iq4nl_lookup4((q.v[i] >> 4) & 0x0F0F0F0F); }
+    const float d = bits_h_f32(hd.v[0] & 0xFFFF) * (float)iq4xs_scale(hd.v[0] >> 16, hd.v[1], ib32) * A.xd[g];
+    return d * (float)(dot16(lo, a0) + dot16(hi, a1));
+  }
+};
+
 // LDS bytes for a row of k activations: int8[k] + float[k/32]*2 + int[k/16]
 static inline size_t mmvq_lds_bytes(int64_t k) { return (size_t)k + (size_t)(k / 32) * 8 + (size_t)(k / 16) * 4; }
 
@@ -457,6 +488,8 @@ static int mmvq_dispatch(const void* w, const void* q, void* y, int type, int dt
     case GGQ_TYPE_Q4_K: return launch_mmvq<GGQ_TYPE_Q4_K>(w, q, y, dtype, k, n_rows, fused, s);
     case GGQ_TYPE_Q5_K: return launch_mmvq<GGQ_TYPE_Q5_K>(w, q, y, dtype, k, n_rows, fused, s);
     case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ4_NL: return launch_mmvq<GGQ_TYPE_IQ4_NL>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ4_XS: return launch_mmvq<GGQ_TYPE_IQ4_XS>(w, q, y, dtype, k, n_rows, fused, s);
     default: return GGQ_ERR_TYPE;
   }
 }

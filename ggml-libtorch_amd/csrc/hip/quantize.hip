@@ -150,7 +150,7 @@ extern "C" int ggq_quantize_q8_1_tiled(const void* x, int x_dtype, void* q, int6
   using namespace ggq;
   if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
   if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
-  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
   if (batch == 0) return GGQ_OK;
   if (!x || !q) return GGQ_ERR_ARG;
   if ((uintptr_t)q & 15) return GGQ_ERR_ALIGN;
@@ -165,7 +165,7 @@ extern "C" int ggq_quantize_q8_1_mmq(const void* x, int x_dtype, void* q, int64_
   using namespace ggq;
   if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
   if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
-  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
   if (batch == 0) return GGQ_OK;
   if (!x || !q) return GGQ_ERR_ARG;
   if ((uintptr_t)q & 15) return GGQ_ERR_ALIGN;

@@ -90,6 +90,8 @@ torch::Tensor ggml_mul_mat_a8(torch::Tensor W, torch::Tensor X, int64_t type, in
   const int dt = ggq_dtype_of(X, "ggml_mul_mat_a8");
   const int64_t col = X.size(x_ndim - 1);
   TORCH_CHECK(row >= 0, "ggml_mul_mat_a8: negative row count");
+  TORCH_CHECK(ggq_mmq_type_supported((int)type), "ggml_mul_mat_a8: no quantised GEMM for ggml type ", type,
+              " (the reference's switch has the same ten cases, HK/ggml/mmq.cu:222-251)");
   check_weight(W, type, row, col, "ggml_mul_mat_a8");
   X = X.contiguous();
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(device_of(X));

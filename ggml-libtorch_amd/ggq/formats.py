@@ -18,6 +18,8 @@ class GGMLType(IntEnum):
     Q4_K = 12
     Q5_K = 13
     Q6_K = 14
+    IQ4_NL = 20   # dequantise + MMVQ only (HK/ggml/ggml_kernel.cu:164-168, 179-183)
+    IQ4_XS = 23
 
 
 # type -> (elements per block, bytes per block)
@@ -26,10 +28,13 @@ BLOCK = {
     GGMLType.Q5_1: (32, 24), GGMLType.Q8_0: (32, 34), GGMLType.Q8_1: (32, 36),
     GGMLType.Q2_K: (256, 84), GGMLType.Q3_K: (256, 110), GGMLType.Q4_K: (256, 144),
     GGMLType.Q5_K: (256, 176), GGMLType.Q6_K: (256, 210),
+    GGMLType.IQ4_NL: (32, 18), GGMLType.IQ4_XS: (256, 136),
 }
 
 WEIGHT_TYPES = [GGMLType.Q4_0, GGMLType.Q4_1, GGMLType.Q5_0, GGMLType.Q5_1, GGMLType.Q8_0,
                 GGMLType.Q2_K, GGMLType.Q3_K, GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K]
+# formats with dequantise + MMVQ kernels only (the reference's ggml_mul_mat_a8 has no case for them)
+IQ_TYPES = [GGMLType.IQ4_NL, GGMLType.IQ4_XS]
 # formats whose MMQ activation scratch stores half2(d, sum) — mmq_need_sum, HK/ggml/mmq.cu:84-106
 NEED_SUM = {GGMLType.Q4_0, GGMLType.Q4_1, GGMLType.Q5_1, GGMLType.Q4_K, GGMLType.Q5_K}
 

@@ -19,6 +19,7 @@ HIP_SYMBOLS = {
     "ggq_block_bytes": (c_int, [c_int]),
     "ggq_row_bytes": (c_int64, [c_int, c_int64]),
     "ggq_type_supported": (c_int, [c_int]),
+    "ggq_mmq_type_supported": (c_int, [c_int]),
     "ggq_mmq_need_sum": (c_int, [c_int]),
     "ggq_mmvq_padded_k": (c_int64, [c_int64]),
     "ggq_mmq_padded_k": (c_int64, [c_int64]),

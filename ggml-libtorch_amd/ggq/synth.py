@@ -14,6 +14,7 @@ _F16_FIELDS = {
     GGMLType.Q4_0: (0, None), GGMLType.Q4_1: (0, 2), GGMLType.Q5_0: (0, None), GGMLType.Q5_1: (0, 2),
     GGMLType.Q8_0: (0, None), GGMLType.Q2_K: (80, 82), GGMLType.Q3_K: (108, None),
     GGMLType.Q4_K: (0, 2), GGMLType.Q5_K: (0, 2), GGMLType.Q6_K: (208, None),
+    GGMLType.IQ4_NL: (0, None), GGMLType.IQ4_XS: (0, None),
 }
 
 

@@ -8,7 +8,10 @@
  *
  * Conventions
  *   - `type` is the ggml type id (HK/ggml/ggml-common.h:1128-1161):
- *     Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8 Q2_K=10 Q3_K=11 Q4_K=12 Q5_K=13 Q6_K=14.
+ *     Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8 Q2_K=10 Q3_K=11 Q4_K=12 Q5_K=13 Q6_K=14,
+ *     and for dequantise + MMVQ only (as in the reference, whose ggml_mul_mat_a8 has no IQ case,
+ *     HK/ggml/mmq.cu:222-251): IQ4_NL=20 IQ4_XS=23.  The other seven IQ ids of the reference's
+ *     dispatch (16-19, 21, 22, 29: HK/ggml/ggml_kernel.cu:145-189) return GGQ_ERR_TYPE.
  *   - W is the raw GGUF tensor payload: `n_rows` rows, each `k/qk` blocks,
  *     row-major, device memory for the ggq_* (GPU) calls.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 1
+#define GGQ_ABI_VERSION 2   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -40,7 +43,9 @@ enum ggq_type {
   GGQ_TYPE_Q3_K = 11,
   GGQ_TYPE_Q4_K = 12,
   GGQ_TYPE_Q5_K = 13,
-  GGQ_TYPE_Q6_K = 14
+  GGQ_TYPE_Q6_K = 14,
+  GGQ_TYPE_IQ4_NL = 20, /* dequantise + MMVQ only */
+  GGQ_TYPE_IQ4_XS = 23  /* dequantise + MMVQ only */
 };
 
 /* activation / output element types (HK/ggml/dispatch_utils.h:14-20) */
@@ -69,8 +74,11 @@ int ggq_block_elems(int type);
 int ggq_block_bytes(int type);
 /* bytes of one weight row of k elements; <0 on error */
 int64_t ggq_row_bytes(int type, int64_t k);
-/* 1 when dequantize / MMVQ / MMQ kernels exist for `type` */
+/* 1 when dequantize / MMVQ kernels exist for `type` */
 int ggq_type_supported(int type);
+/* 1 when the MMQ GEMM (ggq_mul_mat_q*, ggq_quantize_q8_1_mmq / _tiled) exists for `type`: the ten formats of the
+ * reference's ggml_mul_mat_a8 switch (HK/ggml/mmq.cu:222-251) */
+int ggq_mmq_type_supported(int type);
 /* mmq_need_sum (HK/ggml/mmq.cu:84-106): 1 if the MMQ scratch stores half2(d,sum), 0 if float d */
 int ggq_mmq_need_sum(int type);
 

@@ -22,13 +22,15 @@ import numpy as np
 
 Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 2, 3, 6, 7, 8, 9
 Q2_K, Q3_K, Q4_K, Q5_K, Q6_K = 10, 11, 12, 13, 14
+IQ4_NL, IQ4_XS = 20, 23
+KVALUES_IQ4NL = np.array([-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113], np.int32)
 
 BLOCK_ELEMS = {Q4_0: 32, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_0: 32, Q8_1: 32,
-               Q2_K: 256, Q3_K: 256, Q4_K: 256, Q5_K: 256, Q6_K: 256}
+               Q2_K: 256, Q3_K: 256, Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ4_XS: 256}
 BLOCK_BYTES = {Q4_0: 18, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_0: 34, Q8_1: 36,
-               Q2_K: 84, Q3_K: 110, Q4_K: 144, Q5_K: 176, Q6_K: 210}
+               Q2_K: 84, Q3_K: 110, Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ4_XS: 136}
 NAMES = {Q4_0: "Q4_0", Q4_1: "Q4_1", Q5_0: "Q5_0", Q5_1: "Q5_1", Q8_0: "Q8_0",
-         Q2_K: "Q2_K", Q3_K: "Q3_K", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K"}
+         Q2_K: "Q2_K", Q3_K: "Q3_K", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", IQ4_NL: "IQ4_NL", IQ4_XS: "IQ4_XS"}
 WEIGHT_TYPES = [Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K]
 
 
@@ -121,6 +123,23 @@ def unpack_ints(blocks, t):
     raise ValueError(t)
 
 
+def iq4_codes(blocks, t):
+    """IQ4_NL / IQ4_XS (block layouts HK/ggml/ggml-common.h:176-191): codebook values in element order
+    [nb, qk] and the integer scale of each 32-element sub-block [nb, qk/32] (1 for IQ4_NL, ls - 32 for IQ4_XS)."""
+    b = as_blocks(blocks, t)
+    nb = b.shape[0]
+    if t == IQ4_NL:
+        qs = b[:, 2:18]
+        return KVALUES_IQ4NL[np.concatenate([qs & 15, qs >> 4], axis=1)], np.ones((nb, 1), np.int32), _f16(b[:, 0:2])
+    qs = b[:, 8:136].reshape(nb, 8, 16)
+    idx = np.concatenate([qs & 15, qs >> 4], axis=2).reshape(nb, 256)      # sub-block ib: low nibbles then high nibbles
+    sh = b[:, 2].astype(np.int32) | (b[:, 3].astype(np.int32) << 8)
+    ib = np.arange(8)
+    lo = (b[:, 4:8].astype(np.int32)[:, ib // 2] >> (4 * (ib % 2))) & 15
+    hi = (sh[:, None] >> (2 * ib)) & 3
+    return KVALUES_IQ4NL[idx], (lo | (hi << 4)) - 32, _f16(b[:, 0:2])
+
+
 def scales16(blocks, t):
     """(d, dmin_or_m, sc16, mn16): fp16 block scales and per-16-element integer scale/min.
     Legacy formats: sc16/mn16 are None."""
@@ -144,6 +163,9 @@ def scales16(blocks, t):
 
 def dequantize_exact(blocks, t):
     """float64 mathematical definition, no intermediate rounding."""
+    if t in (IQ4_NL, IQ4_XS):
+        v, ls, d = iq4_codes(blocks, t)
+        return d.astype(np.float64)[:, None] * np.repeat(ls, 32, axis=1) * v
     q = unpack_ints(blocks, t).astype(np.float64)
     d, m, sc, mn = scales16(blocks, t)
     d = d.astype(np.float64)[:, None]
@@ -164,6 +186,10 @@ def dequantize_exact(blocks, t):
 def gguf_dequantize(blocks, t):
     """gguf-py ``quants.dequantize`` restated (fp32, gguf-py operation order)."""
     f32 = np.float32
+    if t in (IQ4_NL, IQ4_XS):   # gguf-py: d * kvalues (IQ4_NL); dl = d * (scales - 32), dl * kvalues (IQ4_XS)
+        v, ls, dd = iq4_codes(blocks, t)
+        dl = dd.astype(f32)[:, None] * np.repeat(ls, 32, axis=1).astype(f32) if t == IQ4_XS else dd.astype(f32)[:, None]
+        return dl * v.astype(f32)
     q = unpack_ints(blocks, t)
     d, m, sc, mn = scales16(blocks, t)
     d = d.astype(f32)[:, None]
@@ -197,6 +223,11 @@ def dequantize_f16(blocks, t):
     """fp16-arithmetic sequence of HK/ggml/dequantize.cuh, numpy float16 ops
     (numpy evaluates each float16 op in float32 and rounds once = IEEE fp16)."""
     h = np.float16
+    if t in (IQ4_NL, IQ4_XS):   # fp32: (d * (ls - 32)) * kvalue, one rounding to fp16 (dequantize.cuh:411-415, 428-432)
+        v, ls, d = iq4_codes(blocks, t)
+        with np.errstate(all="ignore"):
+            dl = d.astype(np.float32)[:, None] * np.repeat(ls, 32, axis=1).astype(np.float32) if t == IQ4_XS else d.astype(np.float32)[:, None]
+            return (dl * v.astype(np.float32)).astype(h)
     q = unpack_ints(blocks, t)
     d, m, sc, mn = scales16(blocks, t)
     d = d[:, None]

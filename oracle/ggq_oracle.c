@@ -90,12 +90,28 @@ static inline uint32_t rd32(const uint8_t* p) {
 /* ------------------------------------------------------------------ */
 
 enum { T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9,
-       T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14 };
+       T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14,
+       T_IQ4_NL = 20, T_IQ4_XS = 23 /* HK/ggml/ggml-common.h:1149, 1152 */ };
+
+/* non-linear 4-bit codebook, HK/ggml/ggml-common.h:1060 */
+static const int8_t kvalues_iq4nl[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+/* block_iq4_nl {half d; u8 qs[16]} (ggml-common.h:176-182); block_iq4_xs {half d; u16 scales_h; u8 scales_l[4];
+ * u8 qs[128]} (ggml-common.h:184-191) */
+#define IQ4_NL_D 0
+#define IQ4_NL_QS 2
+#define IQ4_XS_D 0
+#define IQ4_XS_SH 2
+#define IQ4_XS_SL 4
+#define IQ4_XS_QS 8
+static inline int iq4xs_ls(const uint8_t* b, int ib) { /* 6-bit sub-block scale, dequantize.cuh:428 / vecdotq.cuh:876 */
+  const int sh = b[IQ4_XS_SH] | (b[IQ4_XS_SH + 1] << 8);
+  return ((b[IQ4_XS_SL + ib / 2] >> (4 * (ib % 2))) & 0xf) | (((sh >> (2 * ib)) & 3) << 4);
+}
 
 int oracle_block_elems(int type) {
   switch (type) {
-    case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_0: case T_Q8_1: return 32;
-    case T_Q2_K: case T_Q3_K: case T_Q4_K: case T_Q5_K: case T_Q6_K: return 256;
+    case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_0: case T_Q8_1: case T_IQ4_NL: return 32;
+    case T_Q2_K: case T_Q3_K: case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_XS: return 256;
     default: return 0;
   }
 }
@@ -105,6 +121,7 @@ int oracle_block_bytes(int type) {
     case T_Q8_0: return 34; case T_Q8_1: return 36;
     case T_Q2_K: return 84; case T_Q3_K: return 110; case T_Q4_K: return 144;
     case T_Q5_K: return 176; case T_Q6_K: return 210;
+    case T_IQ4_NL: return 18; case T_IQ4_XS: return 136;
     default: return 0;
   }
 }
@@ -255,6 +272,29 @@ int oracle_dequantize_row_f16(int type, const void* vw, uint16_t* y, int64_t k) 
   const uint8_t* w = (const uint8_t*)vw;
   const h16 h8 = oracle_f32_to_f16(8.0f), h16_ = oracle_f32_to_f16(16.0f);
   switch (type) {
+    case T_IQ4_NL: /* dequantize.cuh:399-416: fp32 product d * kvalues, one rounding to fp16 */
+      for (int64_t i = 0; i < k / 32; i++) {
+        const uint8_t* b = w + i * 18;
+        const float d = H(rd16(b + IQ4_NL_D));
+        for (int j = 0; j < 16; ++j) {
+          y[i * 32 + j] = oracle_f32_to_f16(d * (float)kvalues_iq4nl[b[IQ4_NL_QS + j] & 0xf]);
+          y[i * 32 + j + 16] = oracle_f32_to_f16(d * (float)kvalues_iq4nl[b[IQ4_NL_QS + j] >> 4]);
+        }
+      }
+      return 0;
+    case T_IQ4_XS: /* dequantize.cuh:418-433: d = half2float(x.d) * (ls - 32) in fp32, then d * kvalues */
+      for (int64_t i = 0; i < k / 256; i++) {
+        const uint8_t* b = w + i * 136;
+        for (int ib = 0; ib < 8; ++ib) {
+          const float d = H(rd16(b + IQ4_XS_D)) * (float)(iq4xs_ls(b, ib) - 32);
+          const uint8_t* q4 = b + IQ4_XS_QS + 16 * ib;
+          for (int j = 0; j < 16; ++j) {
+            y[i * 256 + 32 * ib + j] = oracle_f32_to_f16(d * (float)kvalues_iq4nl[q4[j] & 0xf]);
+            y[i * 256 + 32 * ib + j + 16] = oracle_f32_to_f16(d * (float)kvalues_iq4nl[q4[j] >> 4]);
+          }
+        }
+      }
+      return 0;
     case T_Q4_0: /* dequantize.cuh:3-16 + dequantize_block :80-99 */
       for (int64_t i = 0; i < k / 32; i++) {
         const uint8_t* b = w + i * 18;
@@ -511,6 +551,24 @@ int oracle_dequantize_row_f64(int type, const void* vw, double* y, int64_t k) {
   int qv[256], sc16[16], mn16[16];
   for (int64_t i = 0; i < k / qk; ++i) {
     const uint8_t* b = w + i * bs;
+    if (type == T_IQ4_NL) {
+      const double d = H(rd16(b));
+      for (int j = 0; j < 16; ++j) {
+        y[i * 32 + j] = d * kvalues_iq4nl[b[IQ4_NL_QS + j] & 0xf];
+        y[i * 32 + j + 16] = d * kvalues_iq4nl[b[IQ4_NL_QS + j] >> 4];
+      }
+      continue;
+    }
+    if (type == T_IQ4_XS) {
+      for (int ib = 0; ib < 8; ++ib) {
+        const double d = (double)H(rd16(b)) * (iq4xs_ls(b, ib) - 32);
+        for (int j = 0; j < 16; ++j) {
+          y[i * 256 + 32 * ib + j] = d * kvalues_iq4nl[b[IQ4_XS_QS + 16 * ib + j] & 0xf];
+          y[i * 256 + 32 * ib + j + 16] = d * kvalues_iq4nl[b[IQ4_XS_QS + 16 * ib + j] >> 4];
+        }
+      }
+      continue;
+    }
     unpack_block(type, b, qv);
     switch (type) {
       case T_Q4_0: { double d = H(rd16(b)); for (int j = 0; j < 32; ++j) y[i * 32 + j] = d * (qv[j] - 8); } break;
@@ -610,6 +668,35 @@ static inline float q8s(const uint8_t* q8, int blk) { return H(rd16(q8 + blk * 3
 /* vec_dot_<fmt>_q8_1(block, q8 blocks aligned with it, iqs) — one lane's contribution */
 static float vec_dot_mmvq(int type, const uint8_t* b, const uint8_t* q8, int iqs) {
   switch (type) {
+    case T_IQ4_NL: { /* vecdotq.cuh:842-864: codebook bytes (get_int_from_table_16, :828-840) x q8, vdr = 2 */
+      int sumi1 = 0, sumi2 = 0;
+      for (int l = 0; l < 2; ++l) {
+        int8_t v1[4], v2[4];
+        for (int c = 0; c < 4; ++c) {
+          const uint8_t q = b[IQ4_NL_QS + 4 * (iqs + l) + c];
+          v1[c] = kvalues_iq4nl[q & 0xf]; v2[c] = kvalues_iq4nl[q >> 4];
+        }
+        sumi1 = dp4a_s(v1, q8qs(q8, 0) + 4 * (iqs + l), sumi1);
+        sumi2 = dp4a_s(v2, q8qs(q8, 0) + 4 * (iqs + l + 4), sumi2);
+      }
+      const float d = H(rd16(b + IQ4_NL_D)) * q8d(q8, 0);
+      return d * (sumi1 + sumi2);
+    }
+    case T_IQ4_XS: { /* vecdotq.cuh:867-888: iqs = 32-element sub-block of the super-block */
+      const int ib32 = iqs;
+      const float d = H(rd16(b + IQ4_XS_D)) * (iq4xs_ls(b, ib32) - 32) * q8d(q8, ib32);
+      int sumi1 = 0, sumi2 = 0;
+      for (int j = 0; j < 4; ++j) {
+        int8_t v1[4], v2[4];
+        for (int c = 0; c < 4; ++c) {
+          const uint8_t q = b[IQ4_XS_QS + 16 * ib32 + 4 * j + c];
+          v1[c] = kvalues_iq4nl[q & 0xf]; v2[c] = kvalues_iq4nl[q >> 4];
+        }
+        sumi1 = dp4a_s(v1, q8qs(q8, ib32) + 4 * j, sumi1);
+        sumi2 = dp4a_s(v2, q8qs(q8, ib32) + 4 * (j + 4), sumi2);
+      }
+      return d * (sumi1 + sumi2);
+    }
     case T_Q4_0: { /* vecdotq.cuh:347-363 + :45-65, vdr = 2 */
       int sumi = 0;
       for (int i = 0; i < 2; ++i) {
@@ -770,8 +857,8 @@ static float vec_dot_mmvq(int type, const uint8_t* b, const uint8_t* q8, int iqs
 
 static int mmvq_qi(int type) {
   switch (type) {
-    case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: return 4;
-    case T_Q8_0: return 8;
+    case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_IQ4_NL: return 4;   /* QI4_NL, ggml-common.h:178 */
+    case T_Q8_0: case T_IQ4_XS: return 8;                                        /* QI4_XS, ggml-common.h:185 */
     case T_Q2_K: case T_Q3_K: return 16;
     case T_Q4_K: case T_Q5_K: case T_Q6_K: return 32;
     default: return 0;
@@ -779,8 +866,8 @@ static int mmvq_qi(int type) {
 }
 static int mmvq_vdr(int type) {
   switch (type) {
-    case T_Q2_K: case T_Q3_K: case T_Q6_K: return 1;
-    default: return 2;
+    case T_Q2_K: case T_Q3_K: case T_Q6_K: case T_IQ4_XS: return 1;   /* mmvq.cuh:198: vdr 1 */
+    default: return 2;                                                 /* IQ4_NL: VDR_Q4_0_Q8_1_MMVQ, mmvq.cuh:189 */
   }
 }
 
@@ -849,6 +936,7 @@ static int idot(const int* a, const int8_t* b, int n) {
 
 int oracle_mul_mat_q(int type, const void* vw, const void* vq8, float* y, float* yabs,
                      int64_t batch, int64_t k, int64_t n_rows) {
+  if (type == T_IQ4_NL || type == T_IQ4_XS) return -1; /* the reference's ggml_mul_mat_a8 has no IQ case (mmq.cu:222-251) */
   const int qk = oracle_block_elems(type), bs = oracle_block_bytes(type);
   if (!qk || type == T_Q8_1 || k % qk) return -1;
   const uint8_t* w = (const uint8_t*)vw;

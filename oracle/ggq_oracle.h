@@ -36,7 +36,7 @@ int oracle_block_bytes(int type);
 int oracle_dequantize_row_f32(int type, const void* w, float* y, int64_t k);
 
 /* GPU semantics (fp16 out, every __h* intrinsic = one IEEE fp16 op):
- * HK/ggml/dequantize.cuh:3-254.  All ten formats. y holds raw fp16 bits. */
+ * HK/ggml/dequantize.cuh:3-254, and :399-433 for IQ4_NL (20) / IQ4_XS (23).  y holds raw fp16 bits. */
 int oracle_dequantize_row_f16(int type, const void* w, uint16_t* y, int64_t k);
 
 /* Exact-arithmetic (double) dequantisation, one value per element, no intermediate
@@ -53,7 +53,7 @@ void oracle_quantize_q8_1(const float* x, void* q, int64_t batch, int64_t k);
 void oracle_quantize_q8_1_mmq(const float* x, void* q, int64_t batch, int64_t k, int need_sum);
 
 /* mul_mat_vec_q (HK/ggml/mmvq.cuh:2-38) with the per-format vec_dot_*_q8_1
- * (HK/ggml/vecdotq.cuh:43-605).  q8: block_q8_1 array of one row (batch 1).
+ * (HK/ggml/vecdotq.cuh:43-605; :842-888 for IQ4_NL / IQ4_XS).  q8: block_q8_1 array of one row (batch 1).
  * y[n_rows] fp32 (before the cast to the output dtype); yabs[n_rows] = sum of |lane terms|
  * (tolerance scale for fp-accumulate comparisons; may be NULL). */
 int oracle_mul_mat_vec_q(int type, const void* w, const void* q8, float* y, float* yabs,

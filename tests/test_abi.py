@@ -6,7 +6,7 @@ import re
 import pytest
 
 from ggq import lib as ggqlib
-from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM
+from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM, IQ_TYPES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,7 +27,7 @@ def test_hip_library_exports_every_symbol():
     L = ggqlib.hip()  # raises if the .so is missing or a symbol is not exported
     for name in ggqlib.HIP_SYMBOLS:
         assert getattr(L, name) is not None
-    assert L.ggq_abi_version() == 1
+    assert L.ggq_abi_version() == 2
 
 
 def test_cpu_library_exports_every_symbol():
@@ -42,10 +42,13 @@ def test_traits_match_format_table():
         assert L.ggq_block_elems(int(t)) == qk and L.ggq_block_bytes(int(t)) == bs
         assert L.ggq_row_bytes(int(t), 4096) == 4096 // qk * bs
     for t in WEIGHT_TYPES:
-        assert L.ggq_type_supported(int(t)) == 1
+        assert L.ggq_type_supported(int(t)) == 1 and L.ggq_mmq_type_supported(int(t)) == 1
         assert L.ggq_mmq_need_sum(int(t)) == int(t in NEED_SUM)
-    for bad in (0, 1, 4, 5, 9, 15, 16, 23, 29, -1):
-        assert L.ggq_type_supported(bad) == 0
+    for t in IQ_TYPES:   # dequantise + MMVQ only, like the reference (its ggml_mul_mat_a8 switch has no IQ case)
+        assert L.ggq_type_supported(int(t)) == 1 and L.ggq_mmq_type_supported(int(t)) == 0
+        assert L.ggq_mmq_tiled_supported(int(t), 4096) == 0
+    for bad in (0, 1, 4, 5, 9, 15, 16, 17, 18, 19, 21, 22, 29, -1):   # incl. the seven IQ ids not built yet
+        assert L.ggq_type_supported(bad) == 0 and L.ggq_mmq_type_supported(bad) == 0
     assert L.ggq_row_bytes(int(GGMLType.Q4_K), 100) == -2 and L.ggq_row_bytes(99, 256) == -1
 
 

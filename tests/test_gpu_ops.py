@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from ggq import synth
-from ggq.formats import GGMLType, WEIGHT_TYPES
+from ggq.formats import GGMLType, WEIGHT_TYPES, IQ_TYPES
 from oracle import ggq_numpy as N
 
 pytestmark = pytest.mark.gpu
@@ -16,6 +16,8 @@ DTYPES = [torch.half, torch.bfloat16, torch.float32]
 HIDDEN_SIZES = [256, 1024]
 NUM_TOKENS = [7, 83, 128, 2048]
 QUANT_TYPES = WEIGHT_TYPES  # the reference lists Q2_K..Q6_K, Q4_0, Q5_0, Q8_0; Q4_1/Q5_1 added
+# dequantise / MMVQ also take the IQ formats built so far (reference: test_cuda_kernels.py:18-25 lists all nine)
+VEC_QUANT_TYPES = WEIGHT_TYPES + IQ_TYPES
 
 
 _SAMPLE_DIR = None
@@ -55,7 +57,7 @@ def ops():
 
 @pytest.mark.parametrize("hidden_size", HIDDEN_SIZES)
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
-@pytest.mark.parametrize("quant_type", QUANT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("quant_type", VEC_QUANT_TYPES, ids=lambda t: t.name)
 @torch.inference_mode()
 def test_dequantize(ops, hidden_size, dtype, quant_type):
     for rows, data in sample_tensors(hidden_size, quant_type):
@@ -66,7 +68,7 @@ def test_dequantize(ops, hidden_size, dtype, quant_type):
 
 @pytest.mark.parametrize("hidden_size", HIDDEN_SIZES)
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
-@pytest.mark.parametrize("quant_type", QUANT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("quant_type", VEC_QUANT_TYPES, ids=lambda t: t.name)
 @torch.inference_mode()
 def test_mmvq(ops, hidden_size, dtype, quant_type):
     torch.manual_seed(0)
@@ -134,6 +136,14 @@ def test_op_errors(ops):
     with pytest.raises(RuntimeError):
         ops.ggml_mul_mat_a8(w[:, :100].contiguous(), x, 2, 4)  # wrong byte count
     assert ops.ggml_mul_mat_a8(w, x[:0], 2, 4).shape == (0, 4)
+    # IQ4_NL shares Q4_0's 18-byte block: dequantise / MMVQ accept id 20, the GEMM op refuses it (the reference's
+    # ggml_mul_mat_a8 silently returns uninitialised memory for it, HK/ggml/mmq.cu:222-251)
+    assert ops.ggml_dequantize(w, 20, 4, 256).shape == (4, 256)
+    assert ops.ggml_mul_mat_vec_a8(w, x, 20, 4).shape == (1, 4)
+    with pytest.raises(RuntimeError):
+        ops.ggml_mul_mat_a8(w, torch.zeros((2, 256), dtype=torch.float16, device="cuda"), 20, 4)
+    with pytest.raises(RuntimeError):
+        ops.ggml_dequantize(w, 21, 4, 256)  # IQ2_S: not built
 
 
 @pytest.mark.parametrize("quant_type", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q6_K, GGMLType.Q4_0], ids=lambda t: t.name)

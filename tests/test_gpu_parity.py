@@ -12,7 +12,7 @@ import torch
 
 from ggq import synth
 from ggq import lib as ggqlib
-from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM, row_bytes
+from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM, IQ_TYPES, row_bytes
 import util
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +27,7 @@ def _x(shape, dtype, seed=0, kind="randn"):
 
 
 # ---------------------------------------------------------------- dequantise
-@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("t", WEIGHT_TYPES + IQ_TYPES, ids=lambda t: t.name)
 def test_dequantize_bit_exact(oracle, t):
     qk, bs = BLOCK[t]
     blocks = np.concatenate([synth.random_blocks(t, 777, seed=11), synth.edge_blocks(t)])
@@ -54,7 +54,7 @@ def test_dequantize_vs_reference_golden(t):
     assert util.same_nan(got, want), f"{t.name}: HIP fp16 != RN_fp16(reference ggml-cpu fp32)"
 
 
-@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("t", WEIGHT_TYPES + IQ_TYPES, ids=lambda t: t.name)
 def test_dequantize_ragged_and_tiny(oracle, t):
     qk, _ = BLOCK[t]
     for nb in (1, 2, 3, 65):  # fewer chunks than one workgroup / odd counts
@@ -129,7 +129,7 @@ def test_quantize_q8_1_tiled_bit_exact(oracle, dtype, t, batch, k):
 
 # ---------------------------------------------------------------- MMVQ
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
-@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("t", WEIGHT_TYPES + IQ_TYPES, ids=lambda t: t.name)
 @pytest.mark.parametrize("k,n_rows", [(256, 37), (1024, 64), (4096, 130)])
 def test_mmvq_vs_oracle(oracle, dtype, t, k, n_rows):
     w = synth.random_weight(t, n_rows, k, seed=k + n_rows)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from ggq import synth
-from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM
+from ggq.formats import GGMLType, BLOCK, WEIGHT_TYPES, NEED_SUM, IQ_TYPES
 from oracle import ggq_numpy as N
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -60,7 +60,24 @@ def test_reference_cpu_op_rejects_kquants_silently_oracle_flags_them(oracle):
         oracle.dequantize_f32(synth.random_blocks(GGMLType.Q4_K, 1), GGMLType.Q4_K, 256)
 
 
-@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+def test_iq4_mmvq_oracle_equals_dequantised_float64_product(oracle):
+    """IQ4_NL / IQ4_XS MMVQ (vecdotq.cuh:842-888) is an exact integer dot times d·d8: equal to
+    dequant(W) · dequant_q8(x) in float64 up to fp32 rounding; the reference has no MMQ for them."""
+    for t in IQ_TYPES:
+        n_rows, k = 9, 1024
+        w = synth.random_weight(t, n_rows, k, seed=12)
+        x = np.random.default_rng(2).standard_normal((1, k)).astype(np.float32)
+        W = N.dequantize_exact(w.reshape(-1, BLOCK[t][1]), t).reshape(n_rows, k)
+        q8 = oracle.quantize_q8_1(x).reshape(1, -1, 36)[:, :k // 32]
+        d8 = q8[:, :, 0:2].copy().view(np.float16)[..., 0].astype(np.float64)
+        xq = (q8[:, :, 4:].view(np.int8).astype(np.float64) * d8[..., None]).reshape(1, k)
+        yv, yabs = oracle.mul_mat_vec_q(w, x, t, n_rows)
+        assert np.all(np.abs(yv - (xq @ W.T)[0]) <= 2e-5 * yabs + 1e-6)
+        with pytest.raises(ValueError):
+            oracle.mul_mat_q(w, np.repeat(x, 4, axis=0), t, n_rows)
+
+
+@pytest.mark.parametrize("t", WEIGHT_TYPES + IQ_TYPES, ids=lambda t: t.name)
 def test_oracle_vs_independent_numpy(oracle, t):
     qk, _ = BLOCK[t]
     blocks = np.concatenate([synth.random_blocks(t, 500, seed=3), synth.edge_blocks(t)])
@@ -112,7 +129,7 @@ def test_integer_unpack_ranges(t):
     assert q.min() >= lo and q.max() <= hi and q.min() == lo and q.max() == hi
 
 
-@pytest.mark.parametrize("t", WEIGHT_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("t", WEIGHT_TYPES + IQ_TYPES, ids=lambda t: t.name)
 def test_fp16_dequant_within_reference_test_tolerance_of_gguf(oracle, t):
     """what the reference's own tests check (atol=1e-2, rtol=4e-2 vs gguf.dequantize) — on |w|<~1 data"""
     qk, _ = BLOCK[t]
