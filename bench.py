@@ -575,6 +575,21 @@ def secondary_configs(L, dev, w_q4k, w_q4k_ring, x128, scratch, args):
     rec("gate_up_Q4_K_Q5_K_batch128_shared_quantisation", gate_up, [rings[Q4_K], rings[Q5_K]],
         algo_bytes_matmul(Q4_K, N_DIM, K_DIM, BATCH) + algo_bytes_matmul(Q5_K, N_DIM, K_DIM, BATCH), 4.0 * BATCH * N_DIM * K_DIM)
     res["gate_up_Q4_K_Q5_K_batch128_shared_quantisation"]["note"] = "compare with the two separate ops: step time + mmq_Q5_K_batch128"
+    # the whole gated FFN front half, silu(x W_gate^T) * (x W_up^T): one quantisation, gate matmul, up matmul whose
+    # write-back applies silu(gate) * acc (GGQ_EPI_SILU_MUL) — against two ops + torch's silu and mul kernels
+    g128 = torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev)
+    def ffn_fused(b):
+        L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
+        L.ggq_mul_mat_q_pretiled(vp(b[0]), vp(scratch), vp(g128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+        L.ggq_mul_mat_q_pretiled_epi(vp(b[1]), vp(scratch), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, 2, vp(g128), cur_stream())
+    def ffn_unfused(b):
+        L.ggq_mul_mat_q(vp(b[0]), vp(x128), vp(g128), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
+        L.ggq_mul_mat_q(vp(b[1]), vp(x128), vp(y128), Q4_K, 1, BATCH, K_DIM, N_DIM, vp(scratch), cur_stream())
+        torch.mul(torch.nn.functional.silu(g128), y128, out=y128)
+    ring2 = rings[Q4_K][1:] + rings[Q4_K][:1]
+    nb2 = 2 * algo_bytes_matmul(Q4_K, N_DIM, K_DIM, BATCH)
+    rec("ffn_gate_up_Q4_K_batch128_fused_silu_mul_epilogue", ffn_fused, [rings[Q4_K], ring2], nb2, 4.0 * BATCH * N_DIM * K_DIM)
+    rec("ffn_gate_up_Q4_K_batch128_two_ops_plus_torch_silu_mul", ffn_unfused, [rings[Q4_K], ring2], nb2, 4.0 * BATCH * N_DIM * K_DIM)
     return res
 
 

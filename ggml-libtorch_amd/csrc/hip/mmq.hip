@@ -581,6 +581,21 @@ namespace ggq {
 //   * K-slice partial sums meet once per unit in LDS.  blockIdx -> unit is XCD-aware: the units of one XCD
 //     are consecutive, so a weight row tile is fetched into one L2 only.
 // ---------------------------------------------------------------------------------------------
+// Fused epilogues of the streamed kernel's write-back (ggq_mul_mat_q_epi; the reference's op has none):
+//   GGQ_EPI_BIAS      y = acc + bias[row]                          aux: bias, n_rows elements of the output dtype
+//   GGQ_EPI_SILU_MUL  y = silu(gate[token, row]) * acc             aux: gate, same [batch, ldy] layout as y
+// applied to the fp32 accumulator before the one rounding to the output dtype.
+struct Epilogue { int kind = GGQ_EPI_NONE; const void* aux = nullptr; };
+template <int DT>
+__device__ __forceinline__ float apply_epilogue(float v, int epi, const void* aux, int64_t yi, int row) {
+  if (epi == GGQ_EPI_BIAS) return v + Elem<DT>::ld(aux, row);
+  if (epi == GGQ_EPI_SILU_MUL) {
+    const float g = Elem<DT>::ld(aux, yi);
+    return v * (g / (1.0f + expf(-g)));
+  }
+  return v;
+}
+
 template <int T> struct StreamCfg {
   using TR = MmqTraits<T>;
   static constexpr bool direct = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;
@@ -637,7 +652,8 @@ template <int T, int DT, int TB, int KS, int NR>
 __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU * KS / 4)) mmq_stream_kernel(const uint8_t* __restrict__ w,
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
-                                                            int64_t ldy, int n_tok_tiles, int n_units, int per_xcd) {
+                                                            int64_t ldy, int n_tok_tiles, int n_units, int per_xcd,
+                                                            int epi, const void* __restrict__ aux) {
   using C = StreamCfg<T>;
   using TR = MmqTraits<T>;
   constexpr int SEG = C::SEG, STAGE = C::STAGE, IPS = C::IPS;
@@ -1011,7 +1027,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int t = t0 + 8 * (i >> 2) + 4 * h + (i & 3);
-        if (t < batch) Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, acc[0][i]);
+        if (t < batch) Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, apply_epilogue<DT>(acc[0][i], epi, aux, (int64_t)t * ldy + n0 + r, n0 + r));
       }
     }
   } else {
@@ -1023,6 +1039,11 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int row = n0 + 8 * qd + 4 * h;
+      if (epi != GGQ_EPI_NONE) {   // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (row + e < n_rows) acc[jj][4 * qd + e] = apply_epilogue<DT>(acc[jj][4 * qd + e], epi, aux, (int64_t)t * ldy + row + e, row + e);
+      }
       if (vec_ok) {
         uint16_t hv[4];
 #pragma unroll
@@ -1047,7 +1068,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 
 template <int T, int DT, int TB, int KS, int NR>
 static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
-                                int64_t ldy, int64_t n_tok_tiles, int64_t n_units, hipStream_t s) {
+                                int64_t ldy, int64_t n_tok_tiles, int64_t n_units, hipStream_t s, Epilogue ep) {
   constexpr int LDS = StreamLaunch<T, TB, KS>::LDS;
   auto kern = mmq_stream_kernel<T, DT, TB, KS, NR>;
   if (LDS > 64 * 1024) {
@@ -1058,14 +1079,14 @@ static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t 
   GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(64 * KS), LDS, s,
                      (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy,
-                     (int)n_tok_tiles, (int)n_units, (int)per_xcd);
+                     (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }
 
 template <int T, int DT, int TB>
 static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n,
-                             int64_t ldy, hipStream_t s) {
+                             int64_t ldy, hipStream_t s, Epilogue ep) {
   const int64_t n_tok_tiles = (batch + 32 * TB - 1) / (32 * TB);
   const int64_t n_units = ((n + 31) / 32) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
@@ -1082,30 +1103,30 @@ static int launch_mmq_stream(const void* w, const void* q8, void* y, int64_t bat
     static const char* et = GGQ_TUNING_ENV("GGQ_MMQ_TRANS");
     const bool trans = et ? et[0] == '1' : true;
     if (trans && batch <= 8)
-      return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s)
-                 : launch_mmq_stream_ks<T, DT, 1, 4, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+      return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s, ep)
+                 : launch_mmq_stream_ks<T, DT, 1, 4, 4>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s, ep);
     if (trans && batch <= 16)
-      return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s)
-                 : launch_mmq_stream_ks<T, DT, 1, 4, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+      return ks8 ? launch_mmq_stream_ks<T, DT, 1, 8, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s, ep)
+                 : launch_mmq_stream_ks<T, DT, 1, 4, 8>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s, ep);
   }
-  if (ks8) return launch_mmq_stream_ks<T, DT, TB, 8, 0>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
-  return launch_mmq_stream_ks<T, DT, TB, 4, 0>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s);
+  if (ks8) return launch_mmq_stream_ks<T, DT, TB, 8, 0>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s, ep);
+  return launch_mmq_stream_ks<T, DT, TB, 4, 0>(w, q8, y, batch, k, n, ldy, n_tok_tiles, n_units, s, ep);
 }
 }  // namespace ggq
 
 namespace ggq {
 template <int T>
 static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int64_t batch, int64_t k,
-                            int64_t n, int64_t ldy, hipStream_t s) {
+                            int64_t n, int64_t ldy, hipStream_t s, Epilogue ep) {
   // 32-token units while one token tile covers the batch, 64-token units beyond (measured r1, Q4_K
   // 11008x4096: batch 32 14.4 vs 20.0 us, batch 128 38.8 vs 29.9 us)
   static const char* e = GGQ_TUNING_ENV("GGQ_MMQ_TB");   // experiments: force 32- or 64-token units
   // (Q2_K's second int8 tile does not fit 168 VGPRs with two token blocks: 168 us spilled vs 54 us)
   const bool one = e ? e[0] == '1' : (batch <= 32 || MmqTraits<T>::two_tiles);
   switch (dt) {
-    case GGQ_F32: return one ? launch_mmq_stream<T, GGQ_F32, 1>(w, q8, y, batch, k, n, ldy, s) : launch_mmq_stream<T, GGQ_F32, 2>(w, q8, y, batch, k, n, ldy, s);
-    case GGQ_F16: return one ? launch_mmq_stream<T, GGQ_F16, 1>(w, q8, y, batch, k, n, ldy, s) : launch_mmq_stream<T, GGQ_F16, 2>(w, q8, y, batch, k, n, ldy, s);
-    case GGQ_BF16: return one ? launch_mmq_stream<T, GGQ_BF16, 1>(w, q8, y, batch, k, n, ldy, s) : launch_mmq_stream<T, GGQ_BF16, 2>(w, q8, y, batch, k, n, ldy, s);
+    case GGQ_F32: return one ? launch_mmq_stream<T, GGQ_F32, 1>(w, q8, y, batch, k, n, ldy, s, ep) : launch_mmq_stream<T, GGQ_F32, 2>(w, q8, y, batch, k, n, ldy, s, ep);
+    case GGQ_F16: return one ? launch_mmq_stream<T, GGQ_F16, 1>(w, q8, y, batch, k, n, ldy, s, ep) : launch_mmq_stream<T, GGQ_F16, 2>(w, q8, y, batch, k, n, ldy, s, ep);
+    case GGQ_BF16: return one ? launch_mmq_stream<T, GGQ_BF16, 1>(w, q8, y, batch, k, n, ldy, s, ep) : launch_mmq_stream<T, GGQ_BF16, 2>(w, q8, y, batch, k, n, ldy, s, ep);
     default: return GGQ_ERR_DTYPE;
   }
 }
@@ -1120,7 +1141,15 @@ extern "C" int ggq_mmq_tiled_supported(int type, int64_t k) {
 extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int type, int dtype,
                                       int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                                       void* stream) {
+  return ggq_mul_mat_q_pretiled_epi(w, q, y, type, dtype, batch, k, n_rows, ldy, GGQ_EPI_NONE, nullptr, stream);
+}
+
+extern "C" int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y, int type, int dtype,
+                                          int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                                          int epilogue, const void* aux, void* stream) {
   using namespace ggq;
+  if (epilogue < GGQ_EPI_NONE || epilogue > GGQ_EPI_SILU_MUL || (epilogue != GGQ_EPI_NONE && !aux)) return GGQ_ERR_ARG;
+  const Epilogue ep{epilogue, aux};
   if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
   if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
   if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
@@ -1132,16 +1161,16 @@ extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   switch (type) {
-    case GGQ_TYPE_Q4_0: return launch_mmq_tiled<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q4_1: return launch_mmq_tiled<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q5_0: return launch_mmq_tiled<GGQ_TYPE_Q5_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q5_1: return launch_mmq_tiled<GGQ_TYPE_Q5_1>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q8_0: return launch_mmq_tiled<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q2_K: return launch_mmq_tiled<GGQ_TYPE_Q2_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q3_K: return launch_mmq_tiled<GGQ_TYPE_Q3_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q4_K: return launch_mmq_tiled<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q5_K: return launch_mmq_tiled<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
-    case GGQ_TYPE_Q6_K: return launch_mmq_tiled<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
+    case GGQ_TYPE_Q4_0: return launch_mmq_tiled<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q4_1: return launch_mmq_tiled<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q5_0: return launch_mmq_tiled<GGQ_TYPE_Q5_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q5_1: return launch_mmq_tiled<GGQ_TYPE_Q5_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q8_0: return launch_mmq_tiled<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q2_K: return launch_mmq_tiled<GGQ_TYPE_Q2_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q3_K: return launch_mmq_tiled<GGQ_TYPE_Q3_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q4_K: return launch_mmq_tiled<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q5_K: return launch_mmq_tiled<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q6_K: return launch_mmq_tiled<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     default: return GGQ_ERR_TYPE;
   }
 }
@@ -1165,6 +1194,16 @@ extern "C" int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type,
   int rc = ggq_quantize_q8_1_mmq(x, dtype, scratch, batch, k, type, stream);
   if (rc != GGQ_OK) return rc;
   return ggq_mul_mat_q_prequant(w, scratch, y, type, dtype, batch, k, n_rows, ldy, stream);
+}
+
+extern "C" int ggq_mul_mat_q_epi(const void* w, const void* x, void* y, int type, int dtype, int64_t batch, int64_t k,
+                                 int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* scratch,
+                                 void* stream) {
+  if (!scratch) return GGQ_ERR_ARG;
+  if (!ggq_mmq_tiled_supported(type, k)) return ggq_mmq_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
+  const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
+  if (rc != GGQ_OK) return rc;
+  return ggq_mul_mat_q_pretiled_epi(w, scratch, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream);
 }
 
 extern "C" int ggq_mul_mat_q(const void* w, const void* x, void* y, int type, int dtype,

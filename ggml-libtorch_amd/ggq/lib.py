@@ -35,6 +35,8 @@ HIP_SYMBOLS = {
     "ggq_mmq_tiled_supported": (c_int, [c_int, c_int64]),
     "ggq_quantize_q8_1_tiled": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "ggq_mul_mat_q_pretiled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "ggq_mul_mat_q_pretiled_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "ggq_mul_mat_q_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ggq_mul_mat_vec_q_prequant": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
 }
 CPU_SYMBOLS = {

@@ -154,6 +154,20 @@ int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int type, int 
                            int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                            void* stream);
 
+/* Fused epilogues (no reference counterpart: ggml_mul_mat_a8 has none; SURVEY §8f rank 3, the caller-side layer).
+ * Applied to the fp32 accumulator in the streamed kernel's write-back, before the one rounding to `dtype`:
+ *   GGQ_EPI_BIAS      y[t, r] = acc + bias[r]                 aux = bias: n_rows elements of `dtype`
+ *   GGQ_EPI_SILU_MUL  y[t, r] = silu(gate[t, r]) * acc        aux = gate: [batch, ldy] of `dtype`, y's layout
+ * (the FFN's silu(x W_gate^T) * (x W_up^T): run the gate matmul, then the up matmul with this epilogue).
+ * ggq_mul_mat_q_epi = ggq_quantize_q8_1_tiled + ggq_mul_mat_q_pretiled_epi (always the streamed kernel). */
+enum ggq_epilogue { GGQ_EPI_NONE = 0, GGQ_EPI_BIAS = 1, GGQ_EPI_SILU_MUL = 2 };
+int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y, int type, int dtype,
+                               int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                               int epilogue, const void* aux, void* stream);
+int ggq_mul_mat_q_epi(const void* w, const void* x, void* y, int type, int dtype,
+                      int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                      int epilogue, const void* aux, void* scratch, void* stream);
+
 /* mul_mat_vec_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1). */
 int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, int dtype,
                                int64_t k, int64_t n_rows, void* stream);

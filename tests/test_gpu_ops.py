@@ -172,3 +172,51 @@ def test_shared_activation_quantisation(ops, quant_type, num_tokens):
     other = GGMLType.Q8_0 if mine else GGMLType.Q4_K   # a format of the other scratch flavour
     with pytest.raises(ValueError):
         linear.QuantizedActivations(x, mine).matmul(wg, other, rows)
+
+
+@pytest.mark.parametrize("quant_type", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q6_K, GGMLType.Q5_1], ids=lambda t: t.name)
+@pytest.mark.parametrize("num_tokens", [3, 12, 40, 128])
+@torch.inference_mode()
+def test_fused_epilogues(ops, quant_type, num_tokens):
+    """GGQ_EPI_BIAS / GGQ_EPI_SILU_MUL in the streamed kernel's write-back (ggq.linear): with fp32 in/out the bias
+    form is acc + bias bit for bit, the gated form silu(gate) * acc within fp32 rounding of the exponential;
+    with fp16 both are ONE rounding of that fp32 value (checked against the fp32 run)."""
+    from ggq import linear
+    from ggq.formats import NEED_SUM
+    hidden, rows = 512, 200      # ragged last 32-row tile
+    w = torch.tensor(synth.random_weight(quant_type, rows, hidden, seed=7, d_scale=2.0 ** -4 if int(quant_type) >= 10 else 1.0), device="cuda")
+    w2 = torch.tensor(synth.random_weight(quant_type, rows, hidden, seed=8, d_scale=2.0 ** -4 if int(quant_type) >= 10 else 1.0), device="cuda")
+    torch.manual_seed(3)
+    x = torch.randn((num_tokens, hidden), device="cuda")
+    bias = torch.randn(rows, device="cuda")
+    qa = linear.QuantizedActivations(x, quant_type in NEED_SUM)
+    acc = qa.matmul(w, quant_type, rows)                       # fp32 accumulators as written without an epilogue
+    yb = linear._matmul_epi(qa, w, quant_type, rows, linear.EPI_BIAS, bias)
+    assert torch.equal(yb, acc + bias)
+    gate = qa.matmul(w2, quant_type, rows)
+    yg = linear._matmul_epi(qa, w, quant_type, rows, linear.EPI_SILU_MUL, gate)
+    want = acc * (gate / (1.0 + torch.exp(-gate)))
+    torch.testing.assert_close(yg, want, rtol=2e-6, atol=1e-6 * float(want.abs().max()))
+    # fp16: module level, against the fp32 path rounded once
+    lin = linear.QuantLinear(w.cpu(), quant_type, hidden, rows, bias=bias.half().cpu()).cuda()
+    y16 = lin(x.half())
+    qa16 = linear.QuantizedActivations(x.half().float().contiguous(), quant_type in NEED_SUM)
+    ref16 = (qa16.matmul(w, quant_type, rows) + bias.half().float())
+    torch.testing.assert_close(y16.float(), ref16, rtol=2e-3, atol=2e-3 * float(ref16.abs().max()))
+
+
+@torch.inference_mode()
+def test_gated_ffn_module(ops):
+    from ggq import linear
+    hidden, inter, t = 512, 768, GGMLType.Q4_K
+    ws = [torch.tensor(synth.random_weight(t, r, k, seed=s, d_scale=2.0 ** -6)) for r, k, s in ((inter, hidden, 1), (inter, hidden, 2), (hidden, inter, 3))]
+    ffn = linear.QuantGatedFFN(ws[0], ws[1], ws[2], t, hidden, inter).cuda()
+    x = torch.randn((2, 20, hidden), device="cuda", dtype=torch.float16)
+    y = ffn(x)
+    assert y.shape == (2, 20, hidden) and torch.isfinite(y).all()
+    x2 = x.reshape(-1, hidden)
+    g = ops.ggml_mul_mat_a8(ffn.w_gate, x2, t, inter).float()
+    u = ops.ggml_mul_mat_a8(ffn.w_up, x2, t, inter).float()
+    h = (torch.nn.functional.silu(g) * u).half()
+    ref = ops.ggml_mul_mat_a8(ffn.down.weight, h, t, hidden).reshape(2, 20, hidden)
+    torch.testing.assert_close(y.float(), ref.float(), rtol=2e-2, atol=2e-2 * float(ref.float().abs().max()))
