@@ -195,14 +195,16 @@ def cpu_config1():
         C = ggqlib.cpu()
         out = np.empty((m, n), np.float32)
         wb = np.ascontiguousarray(w_np)
-        for nt in (1, min(_threads_available(), 64)):
-            C.ggq_cpu_dequantize_f32(wb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), Q4_0, m, n, nt)
+        simd = C.ggq_cpu_simd_name().decode()
+        for nt, sv in ((1, 0), (1, 1), (min(_threads_available(), 64), 1)):
+            C.ggq_cpu_dequantize_f32_ex(wb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), Q4_0, m, n, nt, sv)
             t0 = time.perf_counter()
-            rc = C.ggq_cpu_dequantize_f32(wb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), Q4_0, m, n, nt)
+            rc = C.ggq_cpu_dequantize_f32_ex(wb.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), Q4_0, m, n, nt, sv)
             dt = time.perf_counter() - t0
             assert rc == 0
-            res[f"product_custom_ops_{nt}_threads"] = {"value": round(nb / dt / 1e9, 3), "unit": "GB/s", "cores": nt, "kind": "product",
-                                                       "sample": f"ggq_cpu_dequantize_f32 Q4_0 4096x4096 -> fp32, {dt * 1e3:.1f} ms"}
+            res[f"product_custom_ops_{nt}_threads_{simd if sv else 'scalar'}"] = {
+                "value": round(nb / dt / 1e9, 3), "unit": "GB/s", "cores": nt, "kind": "product",
+                "sample": f"ggq_cpu_dequantize_f32_ex Q4_0 4096x4096 -> fp32, {'vector (' + simd + ')' if sv else 'scalar loops'}, {dt * 1e3:.1f} ms"}
     except Exception as e:  # pragma: no cover
         res["product_custom_ops"] = {"error": str(e)[:200]}
     return res

@@ -41,6 +41,8 @@ HIP_SYMBOLS = {
 }
 CPU_SYMBOLS = {
     "ggq_cpu_dequantize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int]),
+    "ggq_cpu_dequantize_f32_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int]),
+    "ggq_cpu_simd_name": (ctypes.c_char_p, []),
 }
 
 _hip = None
