@@ -600,7 +600,25 @@ template <int T> struct StreamCfg {
   using TR = MmqTraits<T>;
   static constexpr bool direct = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;
   static constexpr int QK = Fmt<T>::QK, BS = Fmt<T>::BS;
-  static constexpr int SE = (QK == 256 || 8 * BS <= 176) ? 256 : 128;   // elements of K per ring stage
+#ifdef GGQ_NO_SPLIT_RING
+  static constexpr bool split = false;
+#else
+  // Legacy 32-element formats: the ring holds a row's stage DE-INTERLEAVED — the quant bytes of its blocks back to
+  // back at 16-byte multiples, the block headers (d / dm / d + qh) behind them — instead of the raw 18/20/22/24/34-
+  // byte blocks: every fragment read of the K loop is then an aligned ds_read_b128 (a misaligned one costs 56
+  // instead of 16 cycles, scripts/ubench_lds_align.hip, and Q8_0 was bound by them).  The copy pays for it with
+  // 2-byte-aligned global loads (one 16-byte piece of one block's quants per lane) and one small header load.
+  static constexpr bool split = QK == 32 && T != GGQ_TYPE_Q4_0;   // (Q4_0: measured neutral, 31.1 vs 30.6 us: its 18-byte blocks keep the raw ring)
+#endif
+  static constexpr int QSB = T == GGQ_TYPE_Q8_0 ? 32 : 16;                 // quant bytes per block
+  static constexpr int QS_OFF = BS - QSB;                                  // ... which end the block
+  static constexpr int HB = (T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1) ? 8 : 4;   // header bytes kept per block (a dword or two from the block start)
+  static constexpr int SE = QK == 256 ? 256 : split ? ((HB == 8 || QSB == 32) ? 128 : 256) : (8 * BS <= 176 ? 256 : 128);   // elements of K per ring stage
+  static constexpr int NB = SE / 32;                                       // blocks of a row in one stage (split form)
+  static constexpr int TPR = NB * (QSB / 16);                              // 16-byte copy tasks per row
+  static constexpr int ROW = NB * QSB + NB * HB;                           // de-interleaved row: quants, then headers
+  static constexpr int SPITCH = (ROW / 16) % 2 ? ROW : ROW + 16;           // odd number of 16-byte units: conflict-free ds_read_b128
+  static constexpr int SNW = 32 * TPR / 64;                                // copy windows (64 tasks each) per stage
   static constexpr int SEG = SE / QK * BS;               // bytes of one row in one stage
   static constexpr int IPS = SE / 64;                    // pair-iterations per stage
   static constexpr int CPR = (SEG + 15) / 16;            // 16-byte chunks per row (the last may overlap)
@@ -609,7 +627,7 @@ template <int T> struct StreamCfg {
   // pitch; the 2-4 tail bytes of a 210/110/84-byte block are parked with a narrow store.  The legacy
   // formats keep their 18/20/22/24/34-byte blocks back to back (their quant bytes are misaligned anyway).
   static constexpr int TAIL = QK == 256 ? SEG % 16 : 0;  // bytes of the last, partial chunk (0: none)
-  static constexpr int PITCH = TAIL ? 16 * CPR : SEG;
+  static constexpr int PITCH = split ? SPITCH : TAIL ? 16 * CPR : SEG;
   // copy windows: one 64-lane load moves up to 64 / CPR rows; the window count is rounded up to a power of two
   // so that the windows tile the 32 rows exactly (no overrun rows: a stage is 32 x PITCH bytes, which lets two
   // eight-wave workgroups of 32-token units share a CU's 160 KB)
@@ -617,9 +635,9 @@ template <int T> struct StreamCfg {
   static constexpr int NWP = NW0 <= 1 ? 1 : NW0 <= 2 ? 2 : NW0 <= 4 ? 4 : NW0 <= 8 ? 8 : NW0 <= 16 ? 16 : 32;
   // ... unless that costs an extra load per iteration (Q8_0: 5 windows over 2 iterations = 3 per iteration, 8
   // would be 4: measured 41 -> 47 us); then the windows keep their natural size and the stage holds the overrun rows
-  static constexpr bool TILING = (NWP + IPS - 1) / IPS == (NW0 + IPS - 1) / IPS;
-  static constexpr int NW = TILING ? NWP : NW0;
-  static constexpr int RPW = TILING ? 32 / NW : 64 / CPR;   // rows per copy window
+  static constexpr bool TILING = split || (NWP + IPS - 1) / IPS == (NW0 + IPS - 1) / IPS;
+  static constexpr int NW = split ? SNW : TILING ? NWP : NW0;
+  static constexpr int RPW = split ? 64 / TPR : TILING ? 32 / NW : 64 / CPR;   // rows per copy window
   static constexpr int WPI = (NW + IPS - 1) / IPS;          // windows per iteration
   static constexpr int STAGE = (((TILING ? 32 : NW * RPW) * PITCH + (TILING ? 0 : 16) + 15) / 16) * 16;
   static constexpr int SBUF = 1024;                      // two copies (pair parity) of [s0 | s1][group of the pair][row] floats
@@ -693,14 +711,41 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   // per-lane constants + scalar (window, stage) terms: no vector multiply in the loop
   const uint32_t lrow_off = (uint32_t)lrow * row_bytes, rmax_off = (uint32_t)rmax * row_bytes;
   const uint32_t lds_lane = (uint32_t)lrow * C::PITCH;
+  // split form: task lane -> (row lane / TPR of the window, block, 16-byte piece of its quants)
+  const int s_lrow = lane / C::TPR, s_blk = (lane % C::TPR) / (C::QSB / 16), s_part = lane % (C::QSB / 16);
+  const int n_blk_row = k / 32;
+  struct Win { u32x4_a2 q; u32x2_a2 h; };
   auto load_window = [&](int st_src, int m) {
+    if constexpr (C::split) {
+      Win wv;
+      const int row = min(m * C::RPW + s_lrow, rmax);                       // clamped to the tile's last valid row
+      const int blk = min(st_src * C::NB + s_blk, n_blk_row - 1);            // K tail: a valid block (zeroed by the n_groups test)
+      const uint8_t* b = wtile + ((uint32_t)row * row_bytes + (uint32_t)blk * C::BS);
+      wv.q = ld_u32x4(b + C::QS_OFF + 16 * s_part);
+      if constexpr (C::HB == 8) wv.h = ld_u32x2(b);
+      else { wv.h.v[0] = ld_u32(b); wv.h.v[1] = 0; }
+      return wv;
+    } else {
+    Win wv;
     const uint32_t sbase = (uint32_t)(m * C::RPW) * row_bytes + (uint32_t)st_src * SEG;   // scalar
     const uint32_t srmax = rmax_off + (uint32_t)st_src * SEG;                             // scalar
     // row m·RPW + lrow, clamped to the tile's last valid row
     const uint32_t roff = lrow <= rmax - m * C::RPW ? sbase + lrow_off : srmax;
-    return ld_u32x4(wtile + (roff + chunk_off(st_src)));
+    wv.q = ld_u32x4(wtile + (roff + chunk_off(st_src)));
+    return wv;
+    }
   };
-  auto store_window = [&](const u32x4_a2& v, int st_src, int buf, int m) {
+  auto store_window = [&](const Win& wv, int st_src, int buf, int m) {
+    if constexpr (C::split) {
+      uint8_t* drow = ring + (uint32_t)(buf * STAGE + (m * C::RPW + s_lrow) * C::PITCH);
+      *(v4i*)(drow + s_blk * C::QSB + 16 * s_part) = v4i{(int)wv.q.v[0], (int)wv.q.v[1], (int)wv.q.v[2], (int)wv.q.v[3]};
+      if (s_part == 0) {
+        if constexpr (C::HB == 8) *(v2i*)(drow + C::NB * C::QSB + 8 * s_blk) = v2i{(int)wv.h.v[0], (int)wv.h.v[1]};
+        else *(uint32_t*)(drow + C::NB * C::QSB + 4 * s_blk) = wv.h.v[0];
+      }
+      return;
+    }
+    const u32x4_a2& v = wv.q;
     uint8_t* dst = ring + (uint32_t)(buf * STAGE + m * C::RPW * C::PITCH) + lds_lane;
     if constexpr (C::TAIL != 0) {
       // aligned 16-byte chunks; the last chunk was loaded ending at the block end: its final TAIL bytes
@@ -745,7 +790,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   v4i B[TB][2];
   uint32_t ds0[TB], ds1[TB];   // d8 (+ sum) words of groups 2p / 2p+1 (separate scalars: never indexed by a lane value)
   v2u dsn[TB];
-  u32x4_a2 wq[C::WPI];         // windows of the next stage in flight
+  Win wq[C::WPI];              // windows of the next stage in flight
   const int p_begin = IPS * st_begin, p_end = IPS * st_end;
   if (p_begin < p_end) {
 #pragma unroll
@@ -784,6 +829,23 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       qs16 = *(const v4i*)(stage + QS + 32 * q + 16 * h);
       hdr = *(const v4i*)stage;
       if constexpr (T == GGQ_TYPE_Q5_K) qh16 = *(const v4i*)(stage + off::Q5_K_QH + 16 * h);
+    } else if constexpr (C::split) {
+      // de-interleaved stage: aligned 16-byte quant pieces + the block's header dword(s)
+      const int blk = 2 * q + h;
+      const v4i q0 = *(const v4i*)(stage + blk * C::QSB);
+      R.q[0] = u32x4_a2{{(uint32_t)q0[0], (uint32_t)q0[1], (uint32_t)q0[2], (uint32_t)q0[3]}};
+      if constexpr (C::QSB == 32) {
+        const v4i q1 = *(const v4i*)(stage + blk * C::QSB + 16);
+        R.q[1] = u32x4_a2{{(uint32_t)q1[0], (uint32_t)q1[1], (uint32_t)q1[2], (uint32_t)q1[3]}};
+      }
+      if constexpr (C::HB == 8) {
+        const v2i hd = *(const v2i*)(stage + C::NB * C::QSB + 8 * blk);
+        if constexpr (T == GGQ_TYPE_Q5_0) { R.s[0] = (uint32_t)hd[0] & 0xFFFF; R.s[1] = ((uint32_t)hd[0] >> 16) | ((uint32_t)hd[1] << 16); }
+        else { R.s[0] = (uint32_t)hd[0]; R.s[1] = (uint32_t)hd[1]; }   // Q5_1: dm, qh
+      } else {
+        const uint32_t hd = *(const uint32_t*)(stage + C::NB * C::QSB + 4 * blk);
+        R.s[0] = (T == GGQ_TYPE_Q4_1) ? hd : (hd & 0xFFFF);
+      }
     } else {
       load_raw<T>(stage, 2 * q + h, R);
     }
