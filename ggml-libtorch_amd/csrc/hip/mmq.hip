@@ -31,6 +31,11 @@
 //   * unpack_raw<T>: one definition of the integer operands and float scales per format (MMQ canon).
 #include "ggq_common.h"
 
+#ifndef GGQ_NO_SBMIN
+#define GGQ_SBMIN 1   // Q4_K / Q5_K: scales + min term once per super-block (fp16 MFMA), see mmq_stream_kernel
+#else
+#define GGQ_SBMIN 0
+#endif
 #ifndef GGQ_ABL
 #define GGQ_ABL 0   // 32: per-wave timestamps in the streamed kernel (scripts/stamps_mmq.py); 0 in every shipped build
 #endif
@@ -541,6 +546,9 @@ extern "C" int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+#ifdef GGQ_DEV_ONLY_Q4K   // development builds (scripts/build_variant.sh): one instantiation, seconds instead of minutes
+  return GGQ_ERR_TYPE;
+#else
   switch (type) {
     case GGQ_TYPE_Q4_0: return launch_mmq<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s);
     case GGQ_TYPE_Q4_1: return launch_mmq<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s);
@@ -554,6 +562,7 @@ extern "C" int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int
     case GGQ_TYPE_Q6_K: return launch_mmq<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s);
     default: return GGQ_ERR_TYPE;
   }
+#endif
 }
 
 namespace ggq {
@@ -595,6 +604,8 @@ __device__ __forceinline__ float apply_epilogue(float v, int epi, const void* au
   }
   return v;
 }
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 template <int T> struct StreamCfg {
   using TR = MmqTraits<T>;
@@ -650,7 +661,11 @@ template <int T> struct StreamCfg {
 // workgroups the kernel is compiled to co-reside per CU
 template <int T, int TB, int KS> struct StreamLaunch {
   static constexpr int RED = (KS - 1) * TB * 16 * 64 * 4;   // (transposed small-batch variant: fewer registers, same bound)
-  static constexpr int LDS = KS * StreamCfg<T>::WAVE > RED ? KS * StreamCfg<T>::WAVE : RED;
+  // per-super-block scales + fp16 min term (SBMIN, see the kernel): needs a 512-byte s8 stash per token block and wave;
+  // not for the eight-slice / 32-token instance, whose two workgroups fill the CU's 160 KB exactly
+  static constexpr bool SBMIN_OK = GGQ_SBMIN && StreamCfg<T>::direct && !(KS == 8 && TB == 1);
+  static constexpr int WAVE = StreamCfg<T>::WAVE + (SBMIN_OK ? TB * 512 : 0);
+  static constexpr int LDS = KS * WAVE > RED ? KS * WAVE : RED;
   // eight slices: 64-token units need ~235 VGPRs (one workgroup per CU); 32-token units stay under 128 and two
   // workgroups share a CU when their rings fit
   static constexpr int WG_PER_CU = KS == 4 ? StreamCfg<T>::OCC
@@ -676,6 +691,14 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   using TR = MmqTraits<T>;
   constexpr int SEG = C::SEG, STAGE = C::STAGE, IPS = C::IPS;
   static_assert(NR == 0 || (TB == 1 && (NR == 4 || NR == 8)), "transposed variant: one token block, 4 or 8 live registers");
+  // Q4_K / Q5_K, lane = token: everything that is per super-block is done once per stage (= super-block) instead of
+  // once per pair — the 8 (scale, min) pairs are decoded with packed byte arithmetic, the row scales of all 8 groups go
+  // to the wave's LDS line in one go, and the min term  Σ_g (-dmin·m_g)[row] · s8_g[token]  is ONE
+  // v_mfma_f32_32x32x16_f16 per token block (K = 8 groups x {hi, lo}: dmin·m_g has 17 significant bits and is split
+  // exactly into two fp16 values; s8 is an fp16 value already; fp16 subnormals are not flushed by the MFMA — checked in
+  // scripts/ubench_f16mfma.hip) instead of four v_mfma_f32_32x32x2_f32: 17 ns instead of 108 ns of matrix pipe per
+  // super-block and token block, and the SIMD does not overlap MFMAs with vector ops (scripts/ubench_overlap.hip).
+  constexpr bool SBMIN = StreamLaunch<T, TB, KS>::SBMIN_OK && NR == 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave]{ ring[2][STAGE]; float sb[2][2][32] }
 
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -689,8 +712,9 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   const int n_groups = k / 32;
   const int n_st = (k + C::SE - 1) / C::SE;
   const int st_begin = (int)((int64_t)ks * n_st / KS), st_end = (int)((int64_t)(ks + 1) * n_st / KS);
-  uint8_t* ring = lds + ks * C::WAVE;
+  uint8_t* ring = lds + ks * StreamLaunch<T, TB, KS>::WAVE;
   float* sb0 = (float*)(ring + 2 * STAGE);   // scale exchange line, double-buffered by pair parity
+  uint32_t* s8l = (uint32_t*)(ring + C::WAVE);   // SBMIN: s8 stash [token block][token][pair of the super-block]
   const int n_tt32 = (batch + 31) / 32;
   const uint32_t lane16 = lane * 16;
   const uint8_t* wtile = w + (int64_t)n0 * row_bytes;
@@ -711,6 +735,8 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   // per-lane constants + scalar (window, stage) terms: no vector multiply in the loop
   const uint32_t lrow_off = (uint32_t)lrow * row_bytes, rmax_off = (uint32_t)rmax * row_bytes;
   const uint32_t lds_lane = (uint32_t)lrow * C::PITCH;
+  const uint32_t w_lane = lrow_off + lcoff;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wtile, 0, (int)((uint32_t)(rmax + 1) * row_bytes), 0x00020000);
   // split form: task lane -> (row lane / TPR of the window, block, 16-byte piece of its quants)
   const int s_lrow = lane / C::TPR, s_blk = (lane % C::TPR) / (C::QSB / 16), s_part = lane % (C::QSB / 16);
   const int n_blk_row = k / 32;
@@ -727,6 +753,12 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       return wv;
     } else {
     Win wv;
+    if constexpr (C::QK == 256) {
+      // descriptor over the tile's valid rows: rows past the tensor's last row read as zeros (never stored)
+      const v4u t = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)w_lane, (int)((uint32_t)(m * C::RPW) * row_bytes + (uint32_t)st_src * SEG), 0);
+      wv.q = u32x4_a2{{t[0], t[1], t[2], t[3]}};
+      return wv;
+    }
     const uint32_t sbase = (uint32_t)(m * C::RPW) * row_bytes + (uint32_t)st_src * SEG;   // scalar
     const uint32_t srmax = rmax_off + (uint32_t)st_src * SEG;                             // scalar
     // row m·RPW + lrow, clamped to the tile's last valid row
@@ -776,6 +808,15 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   gptr abase[TB];
 #pragma unroll
   for (int jj = 0; jj < TB; ++jj) abase[jj] = (gptr)q8 + (int64_t)min((t0 >> 5) + jj, n_tt32 - 1) * 4608;
+  // All activation loads are raw buffer loads: descriptor = the wave-uniform tile pointer (SGPRs, stepped with two scalar
+  // adds per pair), vector offset = a per-lane constant, scalar offset = the uniform remainder.  No 64-bit vector
+  // address arithmetic in the loop and no 64-bit per-lane pointers held in registers.
+  auto arsrc = [&](int jj) { return __builtin_amdgcn_make_buffer_rsrc((void*)abase[jj], 0, (int)0xFFFFFFFFu, 0x00020000); };
+  auto ld_b128 = [&](int jj, uint32_t voff, uint32_t soff) {
+    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(arsrc(jj), (int)voff, (int)soff, 0);
+    return v4i{(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
+  };
+  auto ld_b64 = [&](int jj, uint32_t voff, uint32_t soff) { return __builtin_amdgcn_raw_buffer_load_b64(arsrc(jj), (int)voff, (int)soff, 0); };
   const uint32_t r8 = r * 8;
 
   v16f acc[TB];
@@ -801,9 +842,9 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj) {
       abase[jj] += (int64_t)(p_begin >> 1) * kb_stride + (p_begin & 1) * 2048;
-      B[jj][0] = *(gptr_v4i)(abase[jj] + lane16);
-      B[jj][1] = *(gptr_v4i)(abase[jj] + 1024 + lane16);
-      dsn[jj] = *(gptr_v2u)(abase[jj] + ((p_begin & 1) ? 2304 : 4096) + r8);
+      B[jj][0] = ld_b128(jj, lane16, 0);
+      B[jj][1] = ld_b128(jj, lane16 + 1024, 0);
+      dsn[jj] = ld_b64(jj, r8, (p_begin & 1) ? 2304 : 4096);
     }
   }
 #if GGQ_ABL & 32
@@ -813,7 +854,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 
   for (int p = p_begin; p < p_end; ++p) {
     asm volatile("" : "+v"(magic));   // keep the accumulator preset in registers: hipcc otherwise re-creates it from SGPRs every pair (-2 %)
-    const int st = p / IPS, q = p % IPS;
+    const int st = (int)((unsigned)p / IPS), q = (int)((unsigned)p % IPS);
     // abase[] points at pair p; step to the next pair (the last iteration re-reads its own pair)
     const bool more = p + 1 < p_end;
     const int64_t step = !more ? 0 : (p & 1) ? kb_stride - 2048 : 2048;
@@ -827,7 +868,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
     if constexpr (C::direct) {
       constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : off::Q5_K_QS;
       qs16 = *(const v4i*)(stage + QS + 32 * q + 16 * h);
-      hdr = *(const v4i*)stage;
+      if constexpr (!SBMIN) hdr = *(const v4i*)stage;
       if constexpr (T == GGQ_TYPE_Q5_K) qh16 = *(const v4i*)(stage + off::Q5_K_QH + 16 * h);
     } else if constexpr (C::split) {
       // de-interleaved stage: aligned 16-byte quant pieces + the block's header dword(s)
@@ -849,6 +890,18 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
     } else {
       load_raw<T>(stage, 2 * q + h, R);
     }
+    if constexpr (SBMIN) {
+      if (q == 0) {   // wave-uniform: first pair of a super-block — row scales of its 8 groups to the wave's LDS line
+        const v4i hd = *(const v4i*)stage;   // {d | dmin << 16, scales[0..3], scales[4..7], scales[8..11]}
+        const uint32_t w0 = (uint32_t)hd[1], w2 = (uint32_t)hd[3];
+        // get_scale_min_k4 for the four groups 4h .. 4h+3 of row r at once, one byte each
+        const uint32_t hm = 0u - (uint32_t)h;   // all ones in the upper lane half: bit-select instead of a branch
+        const uint32_t sc4 = (((w2 & 0x0F0F0F0Fu) | ((w0 >> 2) & 0x30303030u)) & hm) | (w0 & 0x3F3F3F3Fu & ~hm);
+        const float dall = bits_h_f32((uint32_t)hd[0] & 0xFFFF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sb0[(4 * h + j) * 32 + r] = dall * (float)((sc4 >> (8 * j)) & 0xFF);
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     // park the windows requested during the previous iteration (slot q of the stage after this one) in the
     // other ring buffer, then request the windows iteration p + 1 will park.  Past the wave's last stage the
@@ -857,16 +910,55 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       const int sw = min(st + 1, st_end - 1);
 #pragma unroll
       for (int i = 0; i < C::WPI; ++i) store_window(wq[i], sw, (st + 1) & 1, min(q * C::WPI + i, C::NW - 1));
-      const int sn = min((p + 1) / IPS + 1, st_end - 1), qn = (p + 1) % IPS;
+      const int sn = min((int)((unsigned)(p + 1) / IPS) + 1, st_end - 1), qn = (int)((unsigned)(p + 1) % IPS);
 #pragma unroll
       for (int i = 0; i < C::WPI; ++i) wq[i] = load_window(sn, min(qn * C::WPI + i, C::NW - 1));
     }
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj) { ds0[jj] = dsn[jj][0]; ds1[jj] = dsn[jj][1]; }
+    if constexpr (SBMIN) {
+      // every pair leaves its two s8 values (high halves of the half2(d8, s8) words) in the wave's stash [jj][token][q];
+      // the last pair of the super-block turns the eight of them into the min term
+#pragma unroll
+      for (int jj = 0; jj < TB; ++jj) s8l[(jj * 32 + r) * 4 + q] = __builtin_amdgcn_perm(ds1[jj], ds0[jj], 0x07060302u);
+      __builtin_amdgcn_wave_barrier();
+      if (q == IPS - 1) {   // wave-uniform
+        const v4i hd = *(const v4i*)stage;
+        const uint32_t w1 = (uint32_t)hd[2], w2 = (uint32_t)hd[3];
+        const uint32_t hm = 0u - (uint32_t)h;
+        const uint32_t m4 = ((((w2 >> 4) & 0x0F0F0F0Fu) | ((w1 >> 2) & 0x30303030u)) & hm) | (w1 & 0x3F3F3F3Fu & ~hm);
+        const float dmin = bits_h_f32((uint32_t)hd[0] >> 16);
+        // -dmin·m_g = hi + lo exactly, both fp16 (RTZ for hi: any rounding leaves a representable remainder).  Only
+        // |dmin·m| beyond the fp16 range cannot be split: then the whole wave takes the 2^-8-scaled form below.
+        const bool big = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(dmin) <= 1024.0f)) != 0;
+        const float dm = big ? dmin * 0.00390625f : dmin;
+        v4i av;   // k order of the lane half: hi(g0) hi(g1) lo(g0) lo(g1) hi(g2) hi(g3) lo(g2) lo(g3), g = group - 4h
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const float p0 = -(dm * (float)((m4 >> (8 * j)) & 0xFF)), p1 = -(dm * (float)((m4 >> (8 * j + 8)) & 0xFF));
+          const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+          av[j] = (int)hb;
+          av[j + 1] = (int)__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0 - bits_h_f32(hb & 0xFFFF), p1 - bits_h_f32(hb >> 16)));
+        }
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+          const v2u x = *(const v2u*)(s8l + (jj * 32 + r) * 4 + 2 * h);   // s8 of groups 4h .. 4h+3 of token r
+          const v4i bv = {(int)x[0], (int)x[0], (int)x[1], (int)x[1]};   // s8(g0) s8(g1) twice, s8(g2) s8(g3) twice: matches av
+          const h8 ah = __builtin_bit_cast(h8, av), bh = __builtin_bit_cast(h8, bv);
+          acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[jj], 0, 0, 0);
+          if (__builtin_expect(big, 0)) {   // cold: the 2^-8-scaled operand was accumulated once, 255 more to go
+            v16f z = {};
+            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, z, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[jj][i] = __builtin_fmaf(z[i], 255.0f, acc[jj][i]);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj) {
       abase[jj] += step;
-      dsn[jj] = *(gptr_v2u)(abase[jj] + ds_off + r8);
+      dsn[jj] = ld_b64(jj, r8, ds_off);
     }
 
     // ---- A fragments of groups 2p, 2p+1 and their scales ----
@@ -885,8 +977,9 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
           a[1][i] |= (int)((((uint32_t)qh16[i] >> (2 * q + 1)) & 0x01010101u) << 4);
         }
       }
-      int sc, mn;   // scale / min of group 2q + h (get_scale_min_k4): q < 2 <=> group < 4
-      if (q < 2) {
+      int sc = 0, mn = 0;   // scale / min of group 2q + h (get_scale_min_k4): q < 2 <=> group < 4
+      if constexpr (SBMIN) {
+      } else if (q < 2) {
         sc = ((uint32_t)hdr[1] >> (16 * q + 8 * h)) & 63;
         mn = ((uint32_t)hdr[2] >> (16 * q + 8 * h)) & 63;
       } else {
@@ -895,8 +988,11 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
         sc = (bb & 0xF) | ((((uint32_t)hdr[1] >> (sh + 6)) & 3) << 4);
         mn = (bb >> 4) | ((((uint32_t)hdr[2] >> (sh + 6)) & 3) << 4);
       }
-      s0 = bits_h_f32((uint32_t)hdr[0] & 0xFFFF) * (float)sc;
-      s1 = -(bits_h_f32((uint32_t)hdr[0] >> 16) * (float)mn);
+      if constexpr (SBMIN) { s0 = 0.0f; s1 = 0.0f; }
+      else {
+        s0 = bits_h_f32((uint32_t)hdr[0] & 0xFFFF) * (float)sc;
+        s1 = -(bits_h_f32((uint32_t)hdr[0] >> 16) * (float)mn);
+      }
     } else {
       uint32_t wv[8], wv2[8];
       unpack_raw<T>(R, 2 * q + h, wv, wv2, s0, s1);
@@ -967,7 +1063,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
           c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a[gg], zero, 0, 0, 0);
           if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[0][gg], a2[gg], zero, 0, 0, 0);
         }
-        B[0][gg] = *(gptr_v4i)(abase[0] + 1024 * gg + lane16);
+        B[0][gg] = ld_b128(0, lane16 + 1024 * gg, 0);
         const float sae = sal[gg], sbe = sbl[gg];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -990,11 +1086,14 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
         }
       }
     } else {
+      if constexpr (SBMIN) sb = sb0 + q * 64;   // the super-block's line [group][row]: groups 2q, 2q+1
+      else {
       sb[h * 32 + r] = s0;
       if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb[64 + h * 32 + r] = s1;
       __builtin_amdgcn_wave_barrier();
+      }
 
-      if constexpr (TR::mfma_min) {
+      if constexpr (TR::mfma_min && !SBMIN) {
         // min term: Σ (-dmin·m)[row, 2p+h] · s8[token, 2p+h] on the matrix pipe
   #pragma unroll
         for (int jj = 0; jj < TB; ++jj)
@@ -1029,7 +1128,9 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
             c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[gg], B[jj][gg], magic, 0, 0, 0);
             if constexpr (TR::two_tiles) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2[gg], B[jj][gg], magic, 0, 0, 0);
           }
-          B[jj][gg] = *(gptr_v4i)(abase[jj] + 1024 * gg + lane16);   // refill in place: a full iteration of lead
+          // refill in place (hipcc sinks these loads to the end of the loop body; pinning them with sched_barrier
+          // spills at 168 VGPRs, and without them the kernel is only 1.2 us faster: not the limiter)
+          B[jj][gg] = ld_b128(jj, lane16 + 1024 * gg, 0);
   #pragma unroll
           for (int qd = 0; qd < 4; ++qd)
   #pragma unroll
@@ -1222,6 +1323,10 @@ extern "C" int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y,
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
+#ifdef GGQ_DEV_ONLY_Q4K
+  if (type != GGQ_TYPE_Q4_K || dtype != GGQ_F16 || batch <= 32) return GGQ_ERR_TYPE;
+  return launch_mmq_stream_ks<GGQ_TYPE_Q4_K, GGQ_F16, 2, 4, 0>(w, q, y, batch, k, n_rows, ldy, (batch + 63) / 64, ((n_rows + 31) / 32) * ((batch + 63) / 64), s, ep);
+#else
   switch (type) {
     case GGQ_TYPE_Q4_0: return launch_mmq_tiled<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     case GGQ_TYPE_Q4_1: return launch_mmq_tiled<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
@@ -1235,6 +1340,7 @@ extern "C" int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y,
     case GGQ_TYPE_Q6_K: return launch_mmq_tiled<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     default: return GGQ_ERR_TYPE;
   }
+#endif
 }
 
 extern "C" int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type, int dtype,
