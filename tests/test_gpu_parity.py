@@ -190,6 +190,28 @@ def test_mmq_streamed_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     util.assert_fp_accumulate(y, ref, yabs, dtype, f"streamed mmq {t.name} b={batch}")
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q5_K], ids=lambda t: t.name)
+@pytest.mark.parametrize("batch", [33, 128])
+def test_mmq_streamed_min_scale_range(oracle, t, batch):
+    """The per-super-block min term of the streamed kernel is one fp16 MFMA over an exact (hi, lo) split of dmin * m:
+    cover the fp16 subnormal range (the remainder is subnormal for every realistic dmin), values next to the 1024
+    threshold, and the scaled cold branch for |dmin * m| beyond the fp16 range (dmin up to 65504)."""
+    k, n_rows = 1024, 96
+    w = synth.random_weight(t, n_rows, k, seed=3).reshape(n_rows, k // 256, -1).copy()
+    specials = np.array([6e-8, -6e-8, 3.0517578125e-05, 6.103515625e-05, -0.000244140625, 0.333251953125, 1.0, 1023.5, 1024.0,
+                         -1024.0, 1025.0, 2048.0, -30000.0, 65504.0, 0.0, -0.0], dtype=np.float16)
+    rng = np.random.default_rng(9)
+    dmin = specials[rng.integers(0, len(specials), size=(n_rows, k // 256))]
+    dmin[:32, :] = np.where(np.abs(dmin[:32, :].astype(np.float32)) > 1024, np.float16(0.0078125), dmin[:32, :])   # one tile stays on the hot path
+    w[:, :, 2:4] = dmin.view(np.uint8).reshape(n_rows, k // 256, 2)
+    w = w.reshape(n_rows, -1)
+    x = _x((batch, k), torch.float32, seed=21)   # fp32 in / out: dmin = 65504 does not overflow the result
+    y = util.gpu_mmq_pretiled(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
+    assert np.isfinite(ref).all()
+    util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"streamed mmq min range {t.name} b={batch}")
+
+
 def test_mmq_streamed_ldy_and_errors(oracle):
     """row pitch (the multi-GPU slab write) + the argument checks of the fragment-major entry points"""
     L = ggqlib.hip()
