@@ -36,6 +36,11 @@
 #else
 #define GGQ_SBMIN 0
 #endif
+#ifndef GGQ_NO_XT
+#define GGQ_XT 1   // fp32-d8 formats: lane = weight row / register = token at every batch (2 instead of 3 vector ops per triple)
+#else
+#define GGQ_XT 0
+#endif
 #ifndef GGQ_ABL
 #define GGQ_ABL 0   // 32: per-wave timestamps in the streamed kernel (scripts/stamps_mmq.py); 0 in every shipped build
 #endif
@@ -546,7 +551,7 @@ extern "C" int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-#ifdef GGQ_DEV_ONLY_Q4K   // development builds (scripts/build_variant.sh): one instantiation, seconds instead of minutes
+#ifdef GGQ_DEV_ONLY   // development builds (scripts/build_variant.sh -DGGQ_DEV_ONLY=<type id>): one instantiation, seconds instead of minutes
   return GGQ_ERR_TYPE;
 #else
   switch (type) {
@@ -699,6 +704,15 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   // scripts/ubench_f16mfma.hip) instead of four v_mfma_f32_32x32x2_f32: 17 ns instead of 108 ns of matrix pipe per
   // super-block and token block, and the SIMD does not overlap MFMAs with vector ops (scripts/ubench_overlap.hip).
   constexpr bool SBMIN = StreamLaunch<T, TB, KS>::SBMIN_OK && NR == 0;
+  // Formats whose token scale d8 is a full fp32 value (Q5_0, Q8_0, Q3_K, Q6_K: need_sum = false) cannot use the exact
+  // two-op apply with lane = token: 12582912·d8 is not representable, so float(C)·d8 costs a subtract and a multiply.
+  // With the MFMA operands swapped (lane = weight row, register = token, as in the small-batch variant but for all 16
+  // registers and every token block) the LANE scalar is the row scale d·sc, which has at most 19 significant bits:
+  // fma(12582912 + C, s, -12582912·s) = RN(C·s) exactly, then one fma with the token's d8 (a per-register value read
+  // from the wave's LDS line): 2 vector ops per (row, token, 32-group) triple instead of 3 (Q6_K: 4 instead of 6).
+  // Measured at batch 128, 11008 x 4096: Q6_K 58.8 -> 56.2 us, Q8_0 42.7 -> 41.7; Q5_0 unchanged and Q3_K 6 % slower (their
+  // loops are bound by the weight copy, not by the apply), so only the first two take it.
+  constexpr bool XT = GGQ_XT && NR == 0 && (T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q6_K);
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave]{ ring[2][STAGE]; float sb[2][2][32] }
 
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -1085,6 +1099,50 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
           }
         }
       }
+    } else if constexpr (XT) {
+      float sal[2], sbl[2] = {0.0f, 0.0f};
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s0), false, false);
+        sal[0] = as_f32((int)sw[0]); sal[1] = as_f32((int)sw[1]);   // scales of groups 2p, 2p+1 of row r, in both halves
+        if constexpr (TR::half_scales) {
+          const auto sw1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, s1), false, false);
+          sbl[0] = as_f32((int)sw1[0]); sbl[1] = as_f32((int)sw1[1]);
+        }
+      }
+      // the fp32 d8 of token r: lanes h = 0 publish group 2p, lanes h = 1 group 2p+1 -> line [token block][group][token]
+#pragma unroll
+      for (int jj = 0; jj < TB; ++jj) sb[jj * 64 + h * 32 + r] = as_f32((int)(h ? ds1[jj] : ds0[jj]));
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const float sae = sal[gg], sbe = sbl[gg];
+        const float nma = -(MAGIC_F * sae), nmb = -(MAGIC_F * sbe);   // exact: the row scales have <= 19 significant bits
+        v4i alo = a[gg], ahi = a[gg];
+        if constexpr (TR::half_scales) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { alo[i] = h == 0 ? a[gg][i] : 0; ahi[i] = h == 1 ? a[gg][i] : 0; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+          v4f dk[4];   // d8 of the tokens of registers 4 qd .. 4 qd + 3: token 8 qd + 4 h + e
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) dk[qd] = *(const v4f*)(sb + jj * 64 + gg * 32 + 8 * qd + 4 * h);
+          v16i c0, c1 = magic;
+          if constexpr (TR::half_scales) {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[jj][gg], alo, magic, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[jj][gg], ahi, magic, 0, 0, 0);
+          } else {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(B[jj][gg], a[gg], magic, 0, 0, 0);
+          }
+          B[jj][gg] = ld_b128(jj, lane16 + 1024 * gg, 0);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float d8 = dk[i >> 2][i & 3];
+            acc[jj][i] = __builtin_fmaf(__builtin_fmaf(as_f32(c0[i]), sae, nma), d8, acc[jj][i]);
+            if constexpr (TR::half_scales) acc[jj][i] = __builtin_fmaf(__builtin_fmaf(as_f32(c1[i]), sbe, nmb), d8, acc[jj][i]);
+          }
+        }
+      }
     } else {
       if constexpr (SBMIN) sb = sb0 + q * 64;   // the super-block's line [group][row]: groups 2q, 2q+1
       else {
@@ -1184,13 +1242,15 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 #pragma unroll
       for (int i = 0; i < NLIVE; ++i) acc[jj][i] += red[((s * TB + jj) * 16 + i) * 64 + lane];
 
-  if constexpr (NR != 0) {
-    // register i = token t0 + 8 (i >> 2) + 4 h + (i & 3), lane & 31 = weight row: 32 consecutive rows per store
+  if constexpr (NR != 0 || XT) {
+    // register i = token t0 + 32 jj + 8 (i >> 2) + 4 h + (i & 3), lane & 31 = weight row: 32 consecutive rows per store
     if (n0 + r < n_rows) {
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const int t = t0 + 8 * (i >> 2) + 4 * h + (i & 3);
-        if (t < batch) Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, apply_epilogue<DT>(acc[0][i], epi, aux, (int64_t)t * ldy + n0 + r, n0 + r));
+      for (int jj = 0; jj < TB; ++jj)
+#pragma unroll
+      for (int i = 0; i < NLIVE; ++i) {
+        const int t = t0 + 32 * jj + 8 * (i >> 2) + 4 * h + (i & 3);
+        if (t < batch) Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, apply_epilogue<DT>(acc[jj][i], epi, aux, (int64_t)t * ldy + n0 + r, n0 + r));
       }
     }
   } else {
@@ -1323,9 +1383,13 @@ extern "C" int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y,
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-#ifdef GGQ_DEV_ONLY_Q4K
-  if (type != GGQ_TYPE_Q4_K || dtype != GGQ_F16 || batch <= 32) return GGQ_ERR_TYPE;
-  return launch_mmq_stream_ks<GGQ_TYPE_Q4_K, GGQ_F16, 2, 4, 0>(w, q, y, batch, k, n_rows, ldy, (batch + 63) / 64, ((n_rows + 31) / 32) * ((batch + 63) / 64), s, ep);
+#ifdef GGQ_DEV_ONLY
+  if (type != GGQ_DEV_ONLY || dtype != GGQ_F16 || batch <= 32) return GGQ_ERR_TYPE;
+#ifndef GGQ_DEV_TB
+#define GGQ_DEV_TB 2
+#endif
+  return launch_mmq_stream_ks<GGQ_DEV_ONLY, GGQ_F16, GGQ_DEV_TB, 4, 0>(w, q, y, batch, k, n_rows, ldy, (batch + 32 * GGQ_DEV_TB - 1) / (32 * GGQ_DEV_TB),
+                                                                      ((n_rows + 31) / 32) * ((batch + 32 * GGQ_DEV_TB - 1) / (32 * GGQ_DEV_TB)), s, ep);
 #else
   switch (type) {
     case GGQ_TYPE_Q4_0: return launch_mmq_tiled<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
