@@ -1145,7 +1145,12 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       }
     } else {
       if constexpr (SBMIN) sb = sb0 + q * 64;   // the super-block's line [group][row]: groups 2q, 2q+1
-      else {
+      else if constexpr (TR::fp16_prod) {
+        // Q4_1 / Q5_1: the line carries the block's half2(d, m) word itself (s0, s1 came from halves: the pack is exact),
+        // so that the per-triple __hmul2(dm, ds8) of the reference is ONE v_pk_mul_f16 against the token's half2(d8, s8)
+        sb[h * 32 + r] = as_f32((int)__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s0, s1)));
+        __builtin_amdgcn_wave_barrier();
+      } else {
       sb[h * 32 + r] = s0;
       if constexpr (TR::n_scale == 2 && !TR::mfma_min) sb[64 + h * 32 + r] = s1;
       __builtin_amdgcn_wave_barrier();
@@ -1164,7 +1169,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           sa[qd] = *(const v4f*)(sb + gg * 32 + 8 * qd + 4 * h);
-          if constexpr (TR::n_scale == 2 && !TR::mfma_min) sbv[qd] = *(const v4f*)(sb + 64 + gg * 32 + 8 * qd + 4 * h);
+          if constexpr (TR::n_scale == 2 && !TR::mfma_min && !TR::fp16_prod) sbv[qd] = *(const v4f*)(sb + 64 + gg * 32 + 8 * qd + 4 * h);
         }
         v4i alo = a[gg], ahi = a[gg];
         if constexpr (TR::half_scales) {   // Q6_K: separate sums over k < 16 and k >= 16 — zero the other half's lanes
@@ -1199,9 +1204,12 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
               // explicit fma + -ffp-contract=off: every accumulator register sees the same instruction
               // sequence, so a row's result does not depend on its position in the tile
               if constexpr (TR::fp16_prod) {   // Q4_1/Q5_1, mmq.cuh:527-529 / :840-842
-                const float lo = (float)((_Float16)sae * (_Float16)bs);
-                const float hi = (float)((_Float16)sbv[qd][e] * (_Float16)bm);
-                acc[jj][i] += __builtin_fmaf(lo, df0 - MAGIC_F, hi);
+                // half2(d d8, m s8) in one packed fp16 multiply, then fma(lo, C, hi) straight from the halves (v_fma_mix_f32)
+                // (asm: hipcc otherwise converts both halves to fp32 first — two more vector ops per triple)
+                const h2 pr = __builtin_bit_cast(h2, sae) * __builtin_bit_cast(h2, dsw);
+                float fr;
+                asm("v_fma_mix_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(fr) : "v"(__builtin_bit_cast(uint32_t, pr)), "v"(df0 - MAGIC_F));
+                acc[jj][i] += fr;
               } else if constexpr (TR::two_tiles) {   // Q2_K: d8 (dall·Σsc q q8 − dmin·Σ m q8), mmq.cuh:47
                 const float df1 = as_f32(c1[i]);
                 acc[jj][i] = __builtin_fmaf(bs, __builtin_fmaf(sae, df0 - MAGIC_F, -(sbv[qd][e] * (df1 - MAGIC_F))), acc[jj][i]);
