@@ -19,6 +19,7 @@
 //   * one wave per row group, ROWS rows in flight per wave for memory-level parallelism,
 //     64-lane shuffle reduction at the end of each row.
 #include "ggq_common.h"
+#include <type_traits>
 
 #ifndef GGQ_MMVQ_UNROLL
 #define GGQ_MMVQ_UNROLL 1
@@ -326,40 +327,47 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
   int* xi16 = (int*)(xs + k / 32);
   const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
 
-  uint32_t touch = 0;
   VSTAMP(0);
   if constexpr (FUSED) {
-    // start the HBM fetch of this wave's first ROWS rows (contiguous bytes) before the quantisation below
-    // (fused launches use 16-wave workgroups, one per CU, and split the rows evenly over all waves:
-    //  every workgroup repeats the quantisation, so there must be few of them)
-    const int n_waves = gridDim.x * 16, wave0 = blockIdx.x * 16 + (threadIdx.x >> 6);
-    const int r0 = (int)((int64_t)wave0 * n_rows / n_waves);
-    const int64_t span = (int64_t)((int)((int64_t)(wave0 + 1) * n_rows / n_waves) - r0) * row_bytes;
-    const uint8_t* p = w + (int64_t)r0 * row_bytes;
-
-    // ---- quantise x -> Q8_1 in LDS: lane = 4 elements, 8 lanes = one 32-group (quantize.hip).  The first
-    //      x loads are issued before the weight touches: vector loads return in order, and x (8 KB, L2-hot
-    //      after the first workgroup) must not queue behind this wave's HBM misses. ----
+    // ---- quantise x -> Q8_1 in LDS (fused launches use 16-wave workgroups, one per CU, and split the rows evenly over
+    //      all waves: every workgroup repeats the quantisation, so there must be few of them).  A byte-per-line
+    //      "touch" of the wave's weight span before this prologue used to be here: with this prologue it costs
+    //      0.7 us warm and 1.1 - 1.7 us cold (every line goes through the texture path twice), so it is gone. ----
+    // Lane l (3 bits b2 b1 b0) of an 8-lane group takes the 4-element chunk c = (b2, b1^b2, b0^b2) of its 32-group: the
+    // three butterfly levels of quantize.hip's sum (element ^16, ^8, ^4 — the fp32 order of the reference's warp
+    // reduction) are then row_half_mirror, quad_perm[2,3,0,1] and quad_perm[1,0,3,2]: DPP modifiers of the add itself
+    // instead of 15 ds_bpermute round trips through the LDS pipe, and the four lanes of a quad hold one 16-element
+    // half, so the per-16 integer sums fall out of the same pass (no second pass, no second barrier).
+    const int l8 = threadIdx.x & 7;
+    const int chunk = ((l8 >> 2) * 7) ^ (l8 & 3);
+    const int g0 = threadIdx.x >> 3;
     float v[4];
-    if (threadIdx.x * 4 < k) {
+    if (g0 < k / 32) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld(q8, threadIdx.x * 4 + i);
+      for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld(q8, g0 * 32 + chunk * 4 + i);
     }
-    for (int64_t o = (threadIdx.x & 63) * 64; o < span; o += 4096) touch += p[o];
-    for (int ix = threadIdx.x * 4; ix < k; ix += 4096) {   // k % 32 == 0: a group is never split
-      if (ix != (int)threadIdx.x * 4) {
+    auto dppf = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false)); };
+    auto dppi = [](int x, auto ctrl) { return __builtin_amdgcn_update_dpp(0, x, decltype(ctrl)::value, 0xF, 0xF, false); };
+    using HM = std::integral_constant<int, 0x141>;   // row_half_mirror: lane <-> 7 - lane
+    using Q2 = std::integral_constant<int, 0x4E>;    // quad_perm [2,3,0,1]: lane ^ 2
+    using Q1 = std::integral_constant<int, 0xB1>;    // quad_perm [1,0,3,2]: lane ^ 1
+    for (int g = g0; g < k / 32; g += 128) {   // k % 32 == 0: a group is never split
+      const int ix = g * 32 + chunk * 4;
+      if (g != g0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld(q8, ix + i);
       }
       float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-      amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-      amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+      amax = fmaxf(amax, dppf(amax, HM{}));
+      amax = fmaxf(amax, dppf(amax, Q2{}));
+      amax = fmaxf(amax, dppf(amax, Q1{}));
       float sm[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-      for (int m = 4; m > 0; m >>= 1)
+      for (int i = 0; i < 4; ++i) sm[i] = sm[i] + dppf(sm[i], HM{});   // element ^ 16
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sm[i] = sm[i] + __shfl_xor(sm[i], m, 64);
+      for (int i = 0; i < 4; ++i) sm[i] = sm[i] + dppf(sm[i], Q2{});   // element ^ 8
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sm[i] = sm[i] + dppf(sm[i], Q1{});   // element ^ 4
       const float sum = (sm[0] + sm[2]) + (sm[1] + sm[3]);
       const float d = amax / 127;
       int qi[4];
@@ -367,9 +375,13 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
       for (int i = 0; i < 4; ++i) qi[i] = amax == 0.0f ? 0 : (int)roundf(v[i] / d);
       ((uint32_t*)xq)[ix >> 2] = (uint32_t)(qi[0] & 0xFF) | ((uint32_t)(qi[1] & 0xFF) << 8) |
                                  ((uint32_t)(qi[2] & 0xFF) << 16) | ((uint32_t)(qi[3] & 0xFF) << 24);
-      if ((ix & 31) == 0) {   // block_q8_1 stores half d, half sum: keep their fp16 rounding
-        xd[ix >> 5] = (float)(_Float16)d;
-        xs[ix >> 5] = (float)(_Float16)sum;
+      int s16 = (qi[0] + qi[1]) + (qi[2] + qi[3]);   // exact: the quad's four chunks are one 16-element half
+      s16 += dppi(s16, Q2{});
+      s16 += dppi(s16, Q1{});
+      if ((l8 & 3) == 0) xi16[2 * g + (l8 >> 2)] = s16;
+      if (l8 == 0) {   // block_q8_1 stores half d, half sum: keep their fp16 rounding
+        xd[g] = (float)(_Float16)d;
+        xs[g] = (float)(_Float16)sum;
       }
     }
   } else {
@@ -387,14 +399,16 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
   VSTAMP(1);
   __syncthreads();
   VSTAMP(2);
-  for (int i = threadIdx.x; i < k / 16; i += (FUSED ? 1024 : 256)) {
-    const v4i a = *(const v4i*)(xq + 16 * i);
-    int s = sdot4(0x01010101, a[0], 0);
-    s = sdot4(0x01010101, a[1], s);
-    s = sdot4(0x01010101, a[2], s);
-    xi16[i] = sdot4(0x01010101, a[3], s);
+  if constexpr (!FUSED) {
+    for (int i = threadIdx.x; i < k / 16; i += 256) {
+      const v4i a = *(const v4i*)(xq + 16 * i);
+      int s = sdot4(0x01010101, a[0], 0);
+      s = sdot4(0x01010101, a[1], s);
+      s = sdot4(0x01010101, a[2], s);
+      xi16[i] = sdot4(0x01010101, a[3], s);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const ActLds A{xq, xd, xs, xi16};
 
   const int lane = threadIdx.x & 63;
@@ -409,7 +423,6 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
     row_begin = wave * rows_per_wave;
     row_end = min(n_rows, (wave + 1) * rows_per_wave);
   }
-  asm volatile("" ::"v"(touch));
   VSTAMP(3);
 
   for (int r0 = row_begin; r0 < row_end; r0 += ROWS) {
