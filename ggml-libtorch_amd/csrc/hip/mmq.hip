@@ -59,6 +59,7 @@ extern "C" int ggq_debug_read_stamps(void* dst, long long n) {
 #endif
 
 #include "mmq_unpack.h"
+#include <type_traits>
 
 namespace ggq {
 
@@ -665,7 +666,7 @@ template <int T> struct StreamCfg {
 // dynamic LDS of a workgroup with KS K-slices (the K-slice reduction aliases the rings) and how many such
 // workgroups the kernel is compiled to co-reside per CU
 template <int T, int TB, int KS> struct StreamLaunch {
-  static constexpr int RED = (KS - 1) * TB * 16 * 64 * 4;   // (transposed small-batch variant: fewer registers, same bound)
+  static constexpr int RED = KS * TB * 16 * 64 * 4;   // (transposed small-batch variant: fewer registers, same bound)
   // per-super-block scales + fp16 min term (SBMIN, see the kernel): needs a 512-byte s8 stash per token block and wave;
   // not for the eight-slice / 32-token instance, whose two workgroups fill the CU's 160 KB exactly
   static constexpr bool SBMIN_OK = GGQ_SBMIN && StreamCfg<T>::direct && !(KS == 8 && TB == 1);
@@ -1232,8 +1233,76 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   GGQ_STAMP(2);
   // ---- K-slice reduction (the rings are dead once every wave has passed its last ds_read) ----
   __syncthreads();
-  float* red = (float*)lds;   // [KS - 1][TB][16][64]
+  float* red = (float*)lds;   // [K-slice][TB][16][64]
   constexpr int NLIVE = NR ? NR : 16;
+  // lane = token, register 4 qd + e = row 8 qd + 4 h + e: one 8-byte store of 4 consecutive rows per (token block, qd)
+  const bool vec_ok = DT != GGQ_F32 && (ldy & 3) == 0 && ((uintptr_t)y & 7) == 0 && n0 + 32 <= n_rows;
+  auto store_quarter = [&](int jj, int qd, float (&v)[4]) {
+    const int t = t0 + 32 * jj + r;
+    if (t >= batch) return;
+    const int row = n0 + 8 * qd + 4 * h;
+    if (epi != GGQ_EPI_NONE) {   // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (row + e < n_rows) v[e] = apply_epilogue<DT>(v[e], epi, aux, (int64_t)t * ldy + row + e, row + e);
+    }
+    if (vec_ok) {
+      uint16_t hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (DT == GGQ_F16) hv[e] = __builtin_bit_cast(uint16_t, (_Float16)v[e]);
+        else hv[e] = Elem<GGQ_BF16>::cvt(v[e]);
+      }
+      uint2 pk;
+      pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+      pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+      *(uint2*)((uint16_t*)y + (int64_t)t * ldy + row) = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (row + e < n_rows) Elem<DT>::st(y, (int64_t)t * ldy + row + e, v[e]);
+    }
+  };
+
+  if constexpr (NR == 0 && !XT && KS == 4) {
+    // All four waves finish the unit: wave q owns register quarter q (rows 8 q + 4 h .. + 3 of every token), publishes
+    // the other three quarters of its partial sums and adds up its own quarter in the fixed order
+    // ((slice 0 + slice 1) + slice 2) + slice 3 — the order the single-wave form below uses, so a result does not depend
+    // on which wave produced it.  A quarter of the LDS reads, adds and stores per wave instead of all of them on wave 0.
+    auto publish = [&](auto QC) {
+      constexpr int Q = decltype(QC)::value;
+#pragma unroll
+      for (int jj = 0; jj < TB; ++jj)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if ((i >> 2) != Q) red[((Q * TB + jj) * 16 + i) * 64 + lane] = acc[jj][i];
+    };
+    auto finish = [&](auto QC) {
+      constexpr int Q = decltype(QC)::value;
+#pragma unroll
+      for (int jj = 0; jj < TB; ++jj) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * Q + e;
+          float sum = Q == 0 ? acc[jj][i] : red[((0 * TB + jj) * 16 + i) * 64 + lane];
+#pragma unroll
+          for (int sl = 1; sl < 4; ++sl) sum += sl == Q ? acc[jj][i] : red[((sl * TB + jj) * 16 + i) * 64 + lane];
+          v[e] = sum;
+        }
+        store_quarter(jj, Q, v);
+      }
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    switch (ks) { case 0: publish(Q0{}); break; case 1: publish(Q1{}); break; case 2: publish(Q2{}); break; default: publish(Q3{}); }
+    __syncthreads();
+    GGQ_STAMP(3);
+    switch (ks) { case 0: finish(Q0{}); break; case 1: finish(Q1{}); break; case 2: finish(Q2{}); break; default: finish(Q3{}); }
+    GGQ_STAMP(4);
+    return;
+  }
+
   if (ks > 0) {
 #pragma unroll
     for (int jj = 0; jj < TB; ++jj)
@@ -1262,37 +1331,13 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       }
     }
   } else {
-  const bool vec_ok = DT != GGQ_F32 && (ldy & 3) == 0 && ((uintptr_t)y & 7) == 0 && n0 + 32 <= n_rows;
 #pragma unroll
-  for (int jj = 0; jj < TB; ++jj) {
-    const int t = t0 + 32 * jj + r;
-    if (t >= batch) continue;
+    for (int jj = 0; jj < TB; ++jj)
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int row = n0 + 8 * qd + 4 * h;
-      if (epi != GGQ_EPI_NONE) {   // wave-uniform
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (row + e < n_rows) acc[jj][4 * qd + e] = apply_epilogue<DT>(acc[jj][4 * qd + e], epi, aux, (int64_t)t * ldy + row + e, row + e);
+      for (int qd = 0; qd < 4; ++qd) {
+        float v[4] = {acc[jj][4 * qd], acc[jj][4 * qd + 1], acc[jj][4 * qd + 2], acc[jj][4 * qd + 3]};
+        store_quarter(jj, qd, v);
       }
-      if (vec_ok) {
-        uint16_t hv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (DT == GGQ_F16) hv[e] = __builtin_bit_cast(uint16_t, (_Float16)acc[jj][4 * qd + e]);
-          else hv[e] = Elem<GGQ_BF16>::cvt(acc[jj][4 * qd + e]);
-        }
-        uint2 pk;
-        pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
-        pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
-        *(uint2*)((uint16_t*)y + (int64_t)t * ldy + row) = pk;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (row + e < n_rows) Elem<DT>::st(y, (int64_t)t * ldy + row + e, acc[jj][4 * qd + e]);
-      }
-    }
-  }
   }
   GGQ_STAMP(4);
 }

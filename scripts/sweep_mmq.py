@@ -1,4 +1,4 @@
-"""Time ggq_mul_mat_q_prequant over a sweep of row counts (HIP events, 100 launches each).
+"""Time ggq_mul_mat_q_prequant / _pretiled over a sweep of row counts (HIP events around a hipGraph of 96 launches; COLD=1: ring of 16 weight tensors).
 usage: python scripts/sweep_mmq.py [type] [batch] rows1 rows2 ..."""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,14 +38,21 @@ if os.environ.get("CHECK") == "1":
     L.ggq_mul_mat_q_prequant(vp(w), vp(scr0), vp(y0), t, 1, batch, K, N, N, st())
     torch.cuda.synchronize()
     print("check: max abs diff vs prequant path", (y0.float() - y1.float()).abs().max().item(), "max |y|", y0.float().abs().max().item())
+COLD = os.environ.get("COLD") == "1"   # consecutive launches cycle 16 distinct weight tensors (> L2 + Infinity Cache)
+ws = [w] + ([w.clone() for _ in range(15)] if COLD else [])
 for N in rows_list:
     y = torch.empty((batch, N), dtype=torch.float16, device="cuda")
-    for _ in range(10):
-        mm(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, st())
+    for i in range(16):
+        mm(vp(ws[i % len(ws)]), vp(scr), vp(y), t, 1, batch, K, N, N, st())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()   # graph replay: no host launch gaps in the figure
+    with torch.cuda.graph(g):
+        for i in range(96):
+            mm(vp(ws[i % len(ws)]), vp(scr), vp(y), t, 1, batch, K, N, N, st())
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(100):
-        mm(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, st())
+    for _ in range(3): g.replay()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 10
-    print(f"type {t} batch {batch} K {K} rows {N}: {us:.2f} us  ({N*K*batch*2/us/1e6:.1f} TOP/s)", flush=True)
+    us = e0.elapsed_time(e1) * 1000 / (3 * 96)
+    print(f"type {t} batch {batch} K {K} rows {N} {'cold' if COLD else 'warm'}: {us:.2f} us  ({N*K*batch*2/us/1e6:.1f} TOP/s)", flush=True)
