@@ -11,6 +11,7 @@
 // int8 out), 8 lanes form a 32-element group, a wave covers 256 elements.  Butterfly
 // levels 16/8/4 are lane exchanges (xor 4/2/1 in lane units), levels 2/1 are in-lane.
 #include "ggq_common.h"
+#include <type_traits>
 
 namespace ggq {
 
@@ -31,24 +32,34 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
                                                             uint8_t* __restrict__ q, int64_t batch,
                                                             int64_t k, int64_t padded, int64_t tok_off) {
   const int64_t t = blockIdx.y + tok_off;
-  const int64_t ix = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  // Lane l (bits b2 b1 b0) of an 8-lane group takes the 4-element chunk c = (b2, b1^b2, b0^b2) of its 32-group, so that the
+  // three cross-lane levels of the reference's warp reduction (element ^16, ^8, ^4: ggml_kernel.cu quantize_q8_1, same fp32
+  // order) are row_half_mirror, quad_perm[2,3,0,1] and quad_perm[1,0,3,2] — DPP modifiers of the max / add itself instead
+  // of ds_bpermute round trips through the LDS pipe (15 per thread before).
+  const int l8 = threadIdx.x & 7;
+  const int64_t ix = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~7) + (((l8 >> 2) * 7) ^ (l8 & 3))) * 4;
   if (ix >= padded) return;  // padded % 32 == 0, so a 32-group is never split by this exit
   float v[4];
   load4<DT>(x, t * k, ix, k, v);
 
+  auto dppf = [](float a, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xF, 0xF, false)); };
+  using HM = std::integral_constant<int, 0x141>;   // row_half_mirror: lane <-> 7 - lane
+  using QP2 = std::integral_constant<int, 0x4E>;   // quad_perm [2,3,0,1]: lane ^ 2
+  using QP1 = std::integral_constant<int, 0xB1>;   // quad_perm [1,0,3,2]: lane ^ 1
   float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-  amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, dppf(amax, HM{}));
+  amax = fmaxf(amax, dppf(amax, QP2{}));
+  amax = fmaxf(amax, dppf(amax, QP1{}));
 
   float sum = 0.0f;
   if (NEED_SUM) {
     float s[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-    for (int m = 4; m > 0; m >>= 1) {  // element masks 16, 8, 4
+    for (int i = 0; i < 4; ++i) s[i] = s[i] + dppf(s[i], HM{});    // element mask 16
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[i] = s[i] + __shfl_xor(s[i], m, 64);
-    }
+    for (int i = 0; i < 4; ++i) s[i] = s[i] + dppf(s[i], QP2{});   // element mask 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = s[i] + dppf(s[i], QP1{});   // element mask 4
     // element mask 2: (e, e^2) -> s0+s2, s1+s3 ; element mask 1: their sum
     sum = (s[0] + s[2]) + (s[1] + s[3]);
   }
