@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
   // from the wave's LDS line): 2 vector ops per (row, token, 32-group) triple instead of 3 (Q6_K: 4 instead of 6).
   // Measured at batch 128, 11008 x 4096: Q6_K 58.8 -> 56.2 us, Q8_0 42.7 -> 41.7; Q5_0 unchanged and Q3_K 6 % slower (their
   // loops are bound by the weight copy, not by the apply), so only the first two take it.
-  constexpr bool XT = GGQ_XT && NR == 0 && (T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q6_K);
+  constexpr bool XT = GGQ_XT && NR == 0 && KS == 4 && (T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q6_K);   // (the eight-slice instances spill with it)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave]{ ring[2][STAGE]; float sb[2][2][32] }
 
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -1264,7 +1264,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
     }
   };
 
-  if constexpr (NR == 0 && !XT && KS == 4) {
+  if constexpr (NR == 0 && !XT && KS == 4 && T != GGQ_TYPE_Q5_0) {   // (Q5_0 sits at 168 VGPRs: the four specialised finishes push it into scratch, 34 -> 39 us)
     // All four waves finish the unit: wave q owns register quarter q (rows 8 q + 4 h .. + 3 of every token), publishes
     // the other three quarters of its partial sums and adds up its own quarter in the fixed order
     // ((slice 0 + slice 1) + slice 2) + slice 3 — the order the single-wave form below uses, so a result does not depend
