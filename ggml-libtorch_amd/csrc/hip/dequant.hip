@@ -17,15 +17,21 @@
 //     a wave's loads cover a contiguous byte range of the weight row;
 //   * no LDS: nothing is reused across lanes except the block header.
 // Measured round 2 (scripts/sweep_dequant.py, 11008 x 4096): with the tensor resident in L2 + Infinity Cache ("warm")
-// Q4_K runs at 70-72 % of the 8 TB/s roof; streamed from HBM with 4 distinct 90 MB outputs ("cold") at 49 %, Q8_0 at
-// 66 %.  On the same box a plain device copy of 86 MB reaches 5.1 TB/s (64 %) cold and a fill 6.2 TB/s.  Tried for
-// the cold case without gain: nontemporal stores (+-0), two chunks per thread (Q4_K 49 -> 40 %), a grid-stride
-// loop that touches the next chunk's bytes one iteration ahead (45 %).
+// Q4_K runs at 72-75 % of the 8 TB/s roof; streamed from HBM with 4 distinct 90 MB outputs ("cold") at 60 % (48 % with
+// one chunk per thread), Q8_0 at 66 %.  On the same box a plain device copy of 86 MB reaches 5.1 TB/s (64 %) cold, a
+// fill 6.2 TB/s, and a kernel with this traffic mix and no arithmetic 5.2-5.7 TB/s (scripts/ubench_expand.hip).
+// Tried for the cold case without gain: nontemporal stores (+-0), two ADJACENT chunks per thread (49 -> 40 %: a lane's
+// stores are then 32 bytes apart), a grid-stride loop that touches the next chunk's bytes one iteration ahead (45 %).
 #include "ggq_common.h"
 
 #ifndef GGQ_DEQUANT_CH
-#define GGQ_DEQUANT_CH(T) 1   // chunks per thread; 2 was measured slower for every format but Q3_K (the two
-                               // 16-byte stores of a lane are 32 bytes apart: Q4_K 73 % -> 62 % of the roof)
+// 8-element chunks per thread, 256 chunks apart (so that every store instruction of a wave still writes 1 KiB
+// contiguous) with ALL loads of the thread issued first.  Streamed from HBM the one-chunk form is bound by latency x
+// resident waves (8192 waves x 1.3 KB per ~2.5 us round trip = 4 TB/s); three chunks in flight per thread give
+// Q4_K 48 -> 60 % of the roof cold (29.8 -> 23.9 us) at +-2 % warm.  Sweep 1/2/3/4/6/8 over all formats in
+// profiles/r02_dequant_chunks.txt: 3 or 4 is best everywhere except Q3_K, whose four 2-byte-aligned loads per chunk
+// bound it in the texture path either way.  The loads can only be hoisted because the decoders are branch-free.
+#define GGQ_DEQUANT_CH(T) ((T) == GGQ_TYPE_Q3_K ? 1 : 3)
 #endif
 
 namespace ggq {
@@ -253,26 +259,27 @@ template <> struct Decode<GGQ_TYPE_IQ4_XS> {
   }
 };
 
-// CH = consecutive 8-element chunks per thread (1 or 2).  Two chunks of the same 16-element run share the block
-// header loads and the sub-scale decode (the compiler merges them), which is what bounded Q3_K / Q6_K.
+// CH = 8-element chunks per thread, 256 apart (GGQ_DEQUANT_CH above).
 template <int T, int CH>
 __global__ void __launch_bounds__(256) dequant_kernel(const uint8_t* __restrict__ w,
                                                       _Float16* __restrict__ out,
                                                       int64_t n_chunks) {
   constexpr int CPB = Fmt<T>::QK / 8;  // 8-element chunks per block
-  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CH;
-  if (c0 >= n_chunks) return;          // n_chunks % CH == 0: every block has an even number of chunks
-  const int64_t ib = c0 / CPB;
-  const int sub = (int)(c0 - ib * CPB);
+  const int64_t c0 = (int64_t)blockIdx.x * (256 * CH) + threadIdx.x;
+  h8 v[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
+    const int64_t c = min(c0 + i * 256, n_chunks - 1);   // clamped, never predicated: the loads of all chunks go out first
+    const int64_t ib = c / CPB;
     _Float16 y[8];
-    Decode<T>::run(w + ib * Fmt<T>::BS, sub + i, y);
-    h8 v;
+    Decode<T>::run(w + ib * Fmt<T>::BS, (int)(c - ib * CPB), y);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = y[e];
-    *(h8*)(out + (c0 + i) * 8) = v;
+    for (int e = 0; e < 8; ++e) v[i][e] = y[e];
   }
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+    if (c0 + i * 256 < n_chunks) *(h8*)(out + (c0 + i * 256) * 8) = v[i];
+
 }
 
 template <int T>
@@ -280,8 +287,7 @@ static int launch_dequant(const void* w, void* out, int64_t k, hipStream_t s) {
   constexpr int CH = GGQ_DEQUANT_CH(T);
   const int64_t n_chunks = k / 8;
   if (n_chunks == 0) return GGQ_OK;
-  const int64_t n_threads = n_chunks / CH;   // QK / 8 is 4 or 32: divisible by CH
-  const int64_t grid = (n_threads + 255) / 256;
+  const int64_t grid = (n_chunks + 256 * CH - 1) / (256 * CH);
   if (grid > 0x7fffffffLL) return GGQ_ERR_SHAPE;
   GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL((dequant_kernel<T, CH>), dim3((unsigned)grid), dim3(256), 0, s,

@@ -101,15 +101,15 @@ __device__ __forceinline__ int iq4xs_scale(uint32_t scales_h, uint32_t scales_l,
 // little-endian dwords s0,s1,s2 of that field (layout: HK/ggml/dequantize.cuh:154-161).
 __device__ __forceinline__ void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t s2, int j,
                                              int& sc, int& mn) {
-  if (j < 4) {
-    sc = (s0 >> (8 * j)) & 63;
-    mn = (s1 >> (8 * j)) & 63;
-  } else {
-    const int jj = j - 4;
-    const uint32_t b = (s2 >> (8 * jj)) & 0xFF;
-    sc = (b & 0xF) | (((s0 >> (8 * jj + 6)) & 3) << 4);
-    mn = (b >> 4) | (((s1 >> (8 * jj + 6)) & 3) << 4);
-  }
+  // branch-free (j is a per-lane value in every caller: a branch runs both sides anyway, and it would split the
+  // scheduling region so that the loads behind it cannot be issued early)
+  const int sh = 8 * (j & 3);
+  const uint32_t a0 = s0 >> sh, a1 = s1 >> sh, b = (s2 >> sh) & 0xFF;
+  const int lo_sc = a0 & 63, lo_mn = a1 & 63;
+  const int hi_sc = (b & 0xF) | ((a0 >> 2) & 0x30);
+  const int hi_mn = (b >> 4) | ((a1 >> 2) & 0x30);
+  sc = j < 4 ? lo_sc : hi_sc;
+  mn = j < 4 ? lo_mn : hi_mn;
 }
 
 // Q3_K 6-bit scale i (0..15) minus 32, from the dwords of the 12-byte field
