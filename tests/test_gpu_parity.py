@@ -342,6 +342,21 @@ def test_mmq_run_to_run_bitwise_reproducible(t, batch):
         assert torch.equal(util.gpu_mmq(w, x, t, n_rows), y0)
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q4_1, GGMLType.Q6_K, GGMLType.Q5_0], ids=lambda t: t.name)
+@pytest.mark.parametrize("batch", [8, 128])
+def test_weight_row_permutation_full_size(t, batch):
+    """Permuting the rows of W permutes the columns of Y bit-exactly: a weight row's result may not depend on its place
+    in the 32-row tile (accumulator register / lane, and — since all four K-slice waves finish a unit, each one a
+    register quarter — on which wave reduced and stored it), nor on the unit or CU it lands on.  Full shape, no oracle."""
+    n_rows, k = 11008, 4096
+    w = synth.random_weight(t, n_rows, k, seed=81)
+    x = _x((batch, k), torch.float16, seed=82)
+    y = util.gpu_mmq(w, x, t, n_rows)
+    perm = np.random.default_rng(5).permutation(n_rows)
+    yp = util.gpu_mmq(np.ascontiguousarray(w[perm]), x, t, n_rows)
+    assert torch.equal(yp, y[:, torch.from_numpy(perm).cuda()]), f"{t.name} batch {batch}: Y(P W) != Y(W) P"
+
+
 @pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q5_1], ids=lambda t: t.name)
 @pytest.mark.parametrize("batch", [8, 16, 77, 128])
 def test_token_permutation_full_size(t, batch):
