@@ -62,13 +62,24 @@ __device__ __forceinline__ uint32_t spread4(uint32_t x) {   // one multiply: the
 
 // UnitDot<T>::run(row pointer, unit index u, activations) -> this lane's partial sum.
 template <int T> struct UnitDot;
+// formats whose UnitDot has the load / dot split (Raw, load(), dot())
+template <int T> struct UnitHasPre {
+  static constexpr bool value = T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 || T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1 ||
+                                T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_K;   // (Q5_K: three 16-byte loads per unit x 3 rows spill at 128 VGPRs)
+};
 
 template <> struct UnitDot<GGQ_TYPE_Q4_0> {  // vecdotq.cuh:45-65, 347-363
   static constexpr int UPB = 1;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  // (load / dot split: the fused kernel issues the loads of a wave's first rows BEFORE it quantises x)
+  struct Raw { uint32_t d; u32x4_a2 q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 18;
-    const float d4 = bits_h_f32(ld_u16(b));
-    const u32x4_a2 q = ld_u32x4(b + off::Q4_0_QS);
+    return Raw{ld_u16(b), ld_u32x4(b + off::Q4_0_QS)};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const float d4 = bits_h_f32(R.d);
+    const u32x4_a2& q = R.q;
     const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
     uint32_t lo[4], hi[4];
 #pragma unroll
@@ -79,10 +90,15 @@ template <> struct UnitDot<GGQ_TYPE_Q4_0> {  // vecdotq.cuh:45-65, 347-363
 };
 template <> struct UnitDot<GGQ_TYPE_Q4_1> {  // vecdotq.cuh:69-91, 365-381
   static constexpr int UPB = 1;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { uint32_t dm; u32x4_a2 q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 20;
-    const uint32_t dm = ld_u32(b);
-    const u32x4_a2 q = ld_u32x4(b + off::Q4_1_QS);
+    return Raw{ld_u32(b), ld_u32x4(b + off::Q4_1_QS)};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const uint32_t dm = R.dm;
+    const u32x4_a2& q = R.q;
     const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
     uint32_t lo[4], hi[4];
 #pragma unroll
@@ -95,11 +111,16 @@ template <> struct UnitDot<GGQ_TYPE_Q4_1> {  // vecdotq.cuh:69-91, 365-381
 };
 template <> struct UnitDot<GGQ_TYPE_Q5_0> {  // vecdotq.cuh:95-124, 383-401
   static constexpr int UPB = 1;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { uint32_t d, qh; u32x4_a2 q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 22;
-    const float d5 = bits_h_f32(ld_u16(b));
-    const uint32_t qh = ld_u32(b + off::Q5_0_QH);
-    const u32x4_a2 q = ld_u32x4(b + off::Q5_0_QS);
+    return Raw{ld_u16(b), ld_u32(b + off::Q5_0_QH), ld_u32x4(b + off::Q5_0_QS)};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const float d5 = bits_h_f32(R.d);
+    const uint32_t qh = R.qh;
+    const u32x4_a2& q = R.q;
     const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
     uint32_t lo[4], hi[4];
 #pragma unroll
@@ -113,11 +134,15 @@ template <> struct UnitDot<GGQ_TYPE_Q5_0> {  // vecdotq.cuh:95-124, 383-401
 };
 template <> struct UnitDot<GGQ_TYPE_Q5_1> {  // vecdotq.cuh:128-158, 403-421
   static constexpr int UPB = 1;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { uint32_t dm, qh; u32x4_a2 q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 24;
-    const uint32_t dm = ld_u32(b);
-    const uint32_t qh = ld_u32(b + off::Q5_1_QH);
-    const u32x4_a2 q = ld_u32x4(b + off::Q5_1_QS);
+    return Raw{ld_u32(b), ld_u32(b + off::Q5_1_QH), ld_u32x4(b + off::Q5_1_QS)};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const uint32_t dm = R.dm, qh = R.qh;
+    const u32x4_a2& q = R.q;
     const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
     uint32_t lo[4], hi[4];
 #pragma unroll
@@ -133,10 +158,16 @@ template <> struct UnitDot<GGQ_TYPE_Q5_1> {  // vecdotq.cuh:128-158, 403-421
 };
 template <> struct UnitDot<GGQ_TYPE_Q8_0> {  // vecdotq.cuh:162-174, 423-438
   static constexpr int UPB = 1;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { uint32_t d; u32x4_a2 q0, q1; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 34;
-    const float d = bits_h_f32(ld_u16(b));
-    const u32x4_a2 q0 = ld_u32x4(b + off::Q8_0_QS), q1 = ld_u32x4(b + off::Q8_0_QS + 16);
+    return Raw{ld_u16(b), ld_u32x4(b + off::Q8_0_QS), ld_u32x4(b + off::Q8_0_QS + 16)};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const float d = bits_h_f32(R.d);
+    const u32x4_a2& q0 = R.q0;
+    const u32x4_a2& q1 = R.q1;
     const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
     const int sumi = dot16(q0.v, a0) + dot16(q1.v, a1);
     return d * A.xd[u] * sumi;
@@ -202,11 +233,16 @@ template <> struct UnitDot<GGQ_TYPE_Q3_K> {  // vecdotq.cuh:227-260, 464-490
 // group 2il (low nibbles) and 16 of group 2il+1 (high nibbles), positions 16hf..16hf+15.
 template <> struct UnitDot<GGQ_TYPE_Q4_K> {  // vecdotq.cuh:264-291, 492-537
   static constexpr int UPB = 8;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { u32x4_a2 hd, q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
+    const uint8_t* b = row + (int64_t)(u >> 3) * 144;
+    return Raw{ld_u32x4(b), ld_u32x4(b + off::Q4_K_QS + 32 * ((u >> 1) & 3) + 16 * (u & 1))};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
     const int ib = u >> 3, il = (u >> 1) & 3, hf = u & 1;
-    const uint8_t* b = row + (int64_t)ib * 144;
-    const u32x4_a2 hd = ld_u32x4(b);
-    const u32x4_a2 q = ld_u32x4(b + off::Q4_K_QS + 32 * il + 16 * hf);
+    const u32x4_a2& hd = R.hd;
+    const u32x4_a2& q = R.q;
     float sumf_d = 0.0f, sumf_m = 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -226,12 +262,17 @@ template <> struct UnitDot<GGQ_TYPE_Q4_K> {  // vecdotq.cuh:264-291, 492-537
 };
 template <> struct UnitDot<GGQ_TYPE_Q5_K> {  // vecdotq.cuh:295-323, 539-585
   static constexpr int UPB = 8;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { u32x4_a2 hd, q, qh; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
+    const uint8_t* b = row + (int64_t)(u >> 3) * 176;
+    return Raw{ld_u32x4(b), ld_u32x4(b + off::Q5_K_QS + 32 * ((u >> 1) & 3) + 16 * (u & 1)), ld_u32x4(b + off::Q5_K_QH + 16 * (u & 1))};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
     const int ib = u >> 3, il = (u >> 1) & 3, hf = u & 1;
-    const uint8_t* b = row + (int64_t)ib * 176;
-    const u32x4_a2 hd = ld_u32x4(b);
-    const u32x4_a2 q = ld_u32x4(b + off::Q5_K_QS + 32 * il + 16 * hf);
-    const u32x4_a2 qh = ld_u32x4(b + off::Q5_K_QH + 16 * hf);
+    const u32x4_a2& hd = R.hd;
+    const u32x4_a2& q = R.q;
+    const u32x4_a2& qh = R.qh;
     float sumf_d = 0.0f, sumf_m = 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -328,6 +369,15 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
   const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
 
   VSTAMP(0);
+  // ---- fused kernel, formats with a load / dot split: the weight bytes of the wave's first ROWS rows (first 64-unit
+  //      step of each) are requested right after the x loads and before x is quantised — their HBM round trip overlaps
+  //      the 1.2 us prologue.  Q4_0 7.6 -> 7.1 us warm / 10.0 -> 9.25 cold, Q4_K 8.7 -> 8.2 / 10.5 -> 9.8, Q8_0 11.2 -> 9.9 /
+  //      15.1 -> 13.5; issued BEFORE the x loads it is a loss (x queues behind the HBM misses), two steps too. ----
+  constexpr bool PRE = FUSED && UnitHasPre<T>::value;
+  constexpr int PS = 1;   // prefetched 64-unit steps per row (Q4_K: two 16-byte loads per unit; two steps spill at 128 VGPRs)
+  struct NoRaw {};
+  using RawT = typename std::conditional<PRE, typename UnitDot<PRE ? T : GGQ_TYPE_Q4_0>::Raw, NoRaw>::type;
+  RawT pre[ROWS][PS];
   if constexpr (FUSED) {
     // ---- quantise x -> Q8_1 in LDS (fused launches use 16-wave workgroups, one per CU, and split the rows evenly over
     //      all waves: every workgroup repeats the quantisation, so there must be few of them).  A byte-per-line
@@ -345,6 +395,17 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
     if (g0 < k / 32) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld(q8, g0 * 32 + chunk * 4 + i);
+    }
+    // (after the x loads: vector loads return in order, and x must not queue behind this wave's HBM misses)
+    if constexpr (PRE) {
+      const int n_waves = gridDim.x * 16, wave0 = blockIdx.x * 16 + (threadIdx.x >> 6);
+      const int rb = (int)((int64_t)wave0 * n_rows / n_waves);
+      const int units0 = k / Fmt<T>::QK * UnitDot<T>::UPB;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int sp = 0; sp < PS; ++sp)   // clamped, never predicated: rows / units past the end repeat valid bytes
+          pre[r][sp] = UnitDot<T>::load(w + (int64_t)min(rb + r, n_rows - 1) * row_bytes, min((int)(threadIdx.x & 63) + 64 * sp, units0 - 1));
     }
     auto dppf = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false)); };
     auto dppi = [](int x, auto ctrl) { return __builtin_amdgcn_update_dpp(0, x, decltype(ctrl)::value, 0xF, 0xF, false); };
@@ -429,8 +490,23 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+    int u_first = lane;
+    if constexpr (PRE) {
+      if (r0 == row_begin) {   // wave-uniform: the prefetched steps of the first row group
+#pragma unroll
+        for (int sp = 0; sp < PS; ++sp) {
+          const int u = lane + 64 * sp;
+          if (u < units) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+              if (r0 + r < row_end) acc[r] += UnitDot<T>::dot(pre[r][sp], u, A);
+          }
+        }
+        u_first = lane + 64 * PS;
+      }
+    }
 #pragma unroll GGQ_MMVQ_UNROLL
-    for (int u = lane; u < units; u += 64) {
+    for (int u = u_first; u < units; u += 64) {
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         if constexpr (FUSED) {   // wave-uniform: a short last group simply skips the row
