@@ -41,6 +41,9 @@
 #else
 #define GGQ_XT 0
 #endif
+#ifndef GGQ_SMALL_RW
+#define GGQ_SMALL_RW 3   // rows in flight per wave in the dot4 kernel (batch <= 4): 3 = a wave's share of 11008 rows; 2 measured slower than 1
+#endif
 #ifndef GGQ_ABL
 #define GGQ_ABL 0   // 32: per-wave timestamps in the streamed kernel (scripts/stamps_mmq.py); 0 in every shipped build
 #endif
@@ -385,94 +388,99 @@ __global__ void __launch_bounds__(1024) mmq_small_kernel(const uint8_t* __restri
   const int64_t row_bytes = (int64_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
   const int row_end = min(n_rows, (wave + 1) * rows_per_wave);
 
-  // steps enumerate (row, 64-group chunk).  (Loading step st+1's bytes ahead of step st's dot products
-  // was measured slower: the extra 24 live registers cost more than the exposed latency.)
+  // RW rows of the wave in flight at once: the raw bytes of all of them are requested before the first dot product
+  // (streamed from HBM a wave with one 16-34-byte load per lane in flight is bound by the round trip, not by bandwidth).
+  // Q4_K 11008 x 4096, op incl. the quantise launch: batch 2 10.2 -> 9.0 us warm / 12.6 -> 11.8 cold, batch 4 13.1 -> 10.9 / 15.0 -> 12.9.
+  constexpr int RW = GGQ_SMALL_RW;
   const int nsteps = (n_groups + 63) / 64;
   const int row_begin = wave * rows_per_wave;
-  const int total = max(0, row_end - row_begin) * nsteps;
-  auto fetch = [&](Raw& R, int st) {
-    const int row = row_begin + st / nsteps;
-    const int G = min(lane + 64 * (st % nsteps), n_groups - 1);  // clamped, never predicated
-    load_raw<T>(w + row * row_bytes, G, R);
-  };
-  Raw Rcur;
-  float acc[NTOK];
+  for (int r0 = row_begin; r0 < row_end; r0 += RW) {
+    float acc[RW][NTOK];
 #pragma unroll
-  for (int t = 0; t < NTOK; ++t) acc[t] = 0.0f;
-  for (int st = 0; st < total; ++st) {
-    const int row = row_begin + st / nsteps;
-    const int us = st % nsteps;
-    const int G = lane + 64 * us;
-    fetch(Rcur, st);
-    if (G < n_groups) {
-      uint32_t wq[8], wq2[8];
-      float s0, s1;
-      unpack_raw<T>(Rcur, G, wq, wq2, s0, s1);
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int t = 0; t < NTOK; ++t) {
-        const v4i a0 = *(const v4i*)(xq + ((size_t)t * n_groups + G) * GP);
-        const v4i a1 = *(const v4i*)(xq + ((size_t)t * n_groups + G) * GP + 16);
-        const uint32_t dsw = xds[t * n_groups + G];
-        float bs, bm = 0.0f;
-        if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
-        else bs = as_f32((int)dsw);
-        int c0 = 0, c1 = 0;
+      for (int t = 0; t < NTOK; ++t) acc[r][t] = 0.0f;
+    for (int us = 0; us < nsteps; ++us) {
+      const int G = lane + 64 * us;
+      const int Gc = min(G, n_groups - 1);   // clamped, never predicated
+      Raw R[RW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          c0 = __builtin_amdgcn_sdot4((int)wq[i], a0[i], c0, false);
-          if constexpr (TR::half_scales) c1 = __builtin_amdgcn_sdot4((int)wq[4 + i], a1[i], c1, false);
-          else c0 = __builtin_amdgcn_sdot4((int)wq[4 + i], a1[i], c0, false);
-          if constexpr (TR::two_tiles) {
-            c1 = __builtin_amdgcn_sdot4((int)wq2[i], a0[i], c1, false);
-            c1 = __builtin_amdgcn_sdot4((int)wq2[4 + i], a1[i], c1, false);
+      for (int r = 0; r < RW; ++r) load_raw<T>(w + (int64_t)min(r0 + r, row_end - 1) * row_bytes, Gc, R[r]);
+      if (G < n_groups) {
+        uint32_t wq[RW][8], wq2[RW][8];
+        float s0[RW], s1[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) unpack_raw<T>(R[r], G, wq[r], wq2[r], s0[r], s1[r]);
+#pragma unroll
+        for (int t = 0; t < NTOK; ++t) {
+          const v4i a0 = *(const v4i*)(xq + ((size_t)t * n_groups + G) * GP);
+          const v4i a1 = *(const v4i*)(xq + ((size_t)t * n_groups + G) * GP + 16);
+          const uint32_t dsw = xds[t * n_groups + G];
+          float bs, bm = 0.0f;
+          if constexpr (TR::need_sum) { bs = bits_h_f32(dsw & 0xFFFF); bm = bits_h_f32(dsw >> 16); }
+          else bs = as_f32((int)dsw);
+#pragma unroll
+          for (int r = 0; r < RW; ++r) {
+            int c0 = 0, c1 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              c0 = __builtin_amdgcn_sdot4((int)wq[r][i], a0[i], c0, false);
+              if constexpr (TR::half_scales) c1 = __builtin_amdgcn_sdot4((int)wq[r][4 + i], a1[i], c1, false);
+              else c0 = __builtin_amdgcn_sdot4((int)wq[r][4 + i], a1[i], c0, false);
+              if constexpr (TR::two_tiles) {
+                c1 = __builtin_amdgcn_sdot4((int)wq2[r][i], a0[i], c1, false);
+                c1 = __builtin_amdgcn_sdot4((int)wq2[r][4 + i], a1[i], c1, false);
+              }
+            }
+            // same float combinations as the MFMA kernels (explicit FMAs, -ffp-contract=off)
+            if constexpr (TR::fp16_prod) {
+              const float lo = (float)((_Float16)s0[r] * (_Float16)bs);
+              const float hi = (float)((_Float16)s1[r] * (_Float16)bm);
+              acc[r][t] += __builtin_fmaf(lo, (float)c0, hi);
+            } else if constexpr (TR::two_tiles) {
+              acc[r][t] = __builtin_fmaf(bs, __builtin_fmaf(s0[r], (float)c0, -(s1[r] * (float)c1)), acc[r][t]);
+            } else if constexpr (TR::half_scales) {
+              acc[r][t] = __builtin_fmaf((float)c0 * bs, s0[r], acc[r][t]);
+              acc[r][t] = __builtin_fmaf((float)c1 * bs, s1[r], acc[r][t]);
+            } else if constexpr (TR::mfma_min) {
+              acc[r][t] = __builtin_fmaf((float)c0 * bs, s0[r], acc[r][t]);
+              acc[r][t] = __builtin_fmaf(s1[r], bm, acc[r][t]);
+            } else {
+              acc[r][t] = __builtin_fmaf((float)c0 * bs, s0[r], acc[r][t]);
+            }
           }
         }
-        // same float combinations as the MFMA kernels (explicit FMAs, -ffp-contract=off)
-        if constexpr (TR::fp16_prod) {
-          const float lo = (float)((_Float16)s0 * (_Float16)bs);
-          const float hi = (float)((_Float16)s1 * (_Float16)bm);
-          acc[t] += __builtin_fmaf(lo, (float)c0, hi);
-        } else if constexpr (TR::two_tiles) {
-          acc[t] = __builtin_fmaf(bs, __builtin_fmaf(s0, (float)c0, -(s1 * (float)c1)), acc[t]);
-        } else if constexpr (TR::half_scales) {
-          acc[t] = __builtin_fmaf((float)c0 * bs, s0, acc[t]);
-          acc[t] = __builtin_fmaf((float)c1 * bs, s1, acc[t]);
-        } else if constexpr (TR::mfma_min) {
-          acc[t] = __builtin_fmaf((float)c0 * bs, s0, acc[t]);
-          acc[t] = __builtin_fmaf(s1, bm, acc[t]);
-        } else {
-          acc[t] = __builtin_fmaf((float)c0 * bs, s0, acc[t]);
-        }
       }
     }
-    if (us != nsteps - 1) continue;
-    // ---- folding butterfly: after the steps with n > 1 values, lane l holds token (l >> shift) ----
-    float v[NTOK];
 #pragma unroll
-    for (int t = 0; t < NTOK; ++t) v[t] = acc[t];
-    int n = NTOK, m = 32;
+    for (int rr = 0; rr < RW; ++rr) {
+      if (r0 + rr >= row_end) break;   // wave-uniform
+      const int row = r0 + rr;
+      // ---- folding butterfly: after the steps with n > 1 values, lane l holds token (l >> shift) ----
+      float v[NTOK];
 #pragma unroll
-    for (; n > 1; n >>= 1, m >>= 1) {
-      const bool upper = (lane & m) != 0;
+      for (int t = 0; t < NTOK; ++t) v[t] = acc[rr][t];
+      int n = NTOK, m = 32;
 #pragma unroll
-      for (int j = 0; j < NTOK / 2; ++j) {
-        if (j < n / 2) {
-          const float keep = upper ? v[j + n / 2] : v[j];
-          const float give = upper ? v[j] : v[j + n / 2];
-          v[j] = keep + __shfl_xor(give, m, 64);
+      for (; n > 1; n >>= 1, m >>= 1) {
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int j = 0; j < NTOK / 2; ++j) {
+          if (j < n / 2) {
+            const float keep = upper ? v[j + n / 2] : v[j];
+            const float give = upper ? v[j] : v[j + n / 2];
+            v[j] = keep + __shfl_xor(give, m, 64);
+          }
         }
       }
+      float r = v[0];
+#pragma unroll
+      for (; m > 0; m >>= 1) r += __shfl_xor(r, m, 64);
+      // the token kept at each fold is selected by the lane bit, MSB first => token = lane / (64 / NTOK)
+      constexpr int LPT = 64 / NTOK;
+      const int t = lane / LPT;
+      if ((lane % LPT) == 0 && t < batch) Elem<DT>::st(y, (int64_t)t * ldy + row, r);
     }
-    float r = v[0];
-#pragma unroll
-    for (; m > 0; m >>= 1) r += __shfl_xor(r, m, 64);
-    // lanes with equal (lane / (64 / NTOK)) now hold the total of token  bitreverse-free index:
-    // the token kept at each fold is selected by the lane bit, MSB first => token = lane / (64 / NTOK)
-    constexpr int LPT = 64 / NTOK;
-    const int t = lane / LPT;
-    if ((lane % LPT) == 0 && t < batch) Elem<DT>::st(y, (int64_t)t * ldy + row, r);
-#pragma unroll
-    for (int tt = 0; tt < NTOK; ++tt) acc[tt] = 0.0f;
   }
 }
 
@@ -488,7 +496,7 @@ static int launch_mmq_small_n(const void* w, const void* q8, void* y, int64_t ba
   }
   // one 16-wave workgroup per CU: the activation staging (tens of KB) is paid once per CU
   int rpw = (int)((n + 256 * 16 - 1) / (256 * 16));
-  rpw = rpw < 1 ? 1 : rpw;
+  rpw = rpw <= 1 ? 1 : (rpw + GGQ_SMALL_RW - 1) / GGQ_SMALL_RW * GGQ_SMALL_RW;   // whole groups of rows in flight
   const int64_t waves = (n + rpw - 1) / rpw;
   const int64_t grid = (waves + 15) / 16;
   GGQ_HIP_PRE_LAUNCH();
