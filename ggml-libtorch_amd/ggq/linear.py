@@ -4,7 +4,8 @@ The reference quantises X inside every ggml_mul_mat_a8 call (HK/ggml/mmq.cu:208-
 multiplies the same X by gate and up projections quantises it twice.  `QuantizedActivations` keeps the
 fragment-major Q8_1 scratch of one X and runs the streamed MMQ kernel against any number of weight matrices of
 the same need_sum class.  Results are bit-identical to `ggml.ggml_mul_mat_a8` for the same (W, X) wherever the
-op itself takes the streamed kernel (batch >= 5; >= 33 for Q6_K, >= 65 for Q8_0: `ggq_mul_mat_q_ld` in mmq.hip) —
+op itself takes the streamed kernel (batch >= 5; >= 9 for Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q4_K, >= 33 for Q6_K, >= 65 for Q8_0:
+`ggq_mul_mat_q_ld` in mmq.hip) —
 there it is the same two kernels with the first one hoisted; at smaller batches the op runs its dot4 / LDS-tile
 kernels, whose fp32 summation order differs (same 1e-3 contract).  (caller-side layer.)
 """

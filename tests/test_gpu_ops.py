@@ -161,7 +161,8 @@ def test_shared_activation_quantisation(ops, quant_type, num_tokens):
     yg, yu = linear.gate_up(x, wg, wu, quant_type, rows)
     rg = ops.ggml_mul_mat_a8(wg, x, quant_type, rows)
     ru = ops.ggml_mul_mat_a8(wu, x, quant_type, rows)
-    streamed_from = {GGMLType.Q8_0: 65, GGMLType.Q6_K: 33}.get(quant_type, 5)
+    streamed_from = {GGMLType.Q8_0: 65, GGMLType.Q6_K: 33, GGMLType.Q4_0: 9, GGMLType.Q4_1: 9, GGMLType.Q5_0: 9, GGMLType.Q5_1: 9,
+                     GGMLType.Q4_K: 9}.get(quant_type, 5)   # ggq_mul_mat_q_ld's routing (mmq.hip)
     if num_tokens >= streamed_from:
         assert torch.equal(yg, rg) and torch.equal(yu, ru)
     else:
