@@ -498,7 +498,7 @@ def main():
                            "warm": {"avg_launch_us": st_warm["us"], "p10": st_warm["p10"], "p90": st_warm["p90"],
                                     "frac": round(bytes_per_step / (st_warm["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
                            "algorithmic_bytes_per_launch": bytes_per_step,
-                           "limiter": "vector-instruction issue (2 FMAs per (row, token, 32-group) triple), not HBM and not the matrix pipe: DESIGN.md §5.4",
+                           "limiter": "the SIMD's own arithmetic, not HBM: 2 exact FMAs per (row, token, 32-group) triple + the int8 MFMAs, which this SIMD does not overlap with packed FMAs (scripts/ubench_overlap.hip); DESIGN.md §5.4",
                            "int8_mfma_TOPs": round(ops / (st_cold["us"] * 1e-6) / 1e12, 2),
                            "frac_int8_mfma_peak": round(ops / (st_cold["us"] * 1e-6) / 1e12 / INT8_PEAK_TOPS, 4),
                            "note": "duration = HIP-event time of 208 back-to-back launches / 208 on the launch stream, median of 9 repeats"}
