@@ -23,7 +23,7 @@ INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 ARCH = "gfx950"
 EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX")
 
-HIP_SOURCES = ["dequant", "quantize", "mmvq", "mmq"]
+HIP_SOURCES = ["dequant", "quantize", "mmvq", "mmq", "peer"]
 TRAITS_SRC = os.path.join(CSRC, "core", "traits.cpp")
 # No implicit fused-multiply-add contraction anywhere: the fp16 dequantise sequence and the Q8_1
 # quantiser must round after every operation exactly like the reference's intrinsics, and in the

@@ -95,6 +95,71 @@ class SlabGather:
         return unpermute_gathered(self.buf)
 
 
+class PeerSlabGather:
+    """Gather without a collective: every rank maps the other ranks' [P, batch, rows] buffers (ggq_peer_export / _import:
+    HIP IPC) and WRITES its slab straight into slot `rank` of each of them — device-to-device stores that cross xGMI
+    when the ranks own different GPUs.  Same interface as SlabGather (`local`, `gather()`, `buf`, `batch_major()`).
+
+    `local` is the rank's slot of its own buffer: the matmul writes there (out= / ldy).  `gather()` pushes that slab to
+    the peers on the current stream, drains the stream and meets the other ranks at a barrier of the (CPU-capable)
+    process group, after which `buf` holds every rank's slab.  This is the first step of the direct-write path of
+    SURVEY 8e: the copy still follows the kernel instead of being the kernel's own stores, and the hand-off is a host
+    barrier rather than a device flag; it needs no RCCL and has been exercised with two processes sharing one GPU
+    (tests/test_peer_gather.py) — no multi-GPU node was available to this build."""
+
+    def __init__(self, batch: int, n_rows: int, dtype, device, group=None):
+        import ctypes
+        from . import lib as ggqlib
+        self.L = ggqlib.hip()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if n_rows % self.world:
+            raise ValueError("PeerSlabGather needs equal shards (n_rows % world_size == 0)")
+        self.batch, self.rows = batch, n_rows // self.world
+        self.buf = torch.empty((self.world, batch, self.rows), dtype=dtype, device=device)
+        handle = (ctypes.c_ubyte * 64)()
+        off = ctypes.c_int64(0)
+        ggqlib.check(self.L.ggq_peer_export(ctypes.c_void_p(self.buf.data_ptr()), handle, ctypes.byref(off)), "ggq_peer_export")
+        mine = (bytes(handle), int(off.value))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=group)
+        self._peer_ptr, self._peer_off = {}, {}
+        for p, (h, o) in enumerate(everyone):
+            if p == self.rank:
+                continue
+            ptr = ctypes.c_void_p()
+            hb = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+            ggqlib.check(self.L.ggq_peer_import(hb, o, ctypes.byref(ptr)), "ggq_peer_import")
+            self._peer_ptr[p], self._peer_off[p] = ptr.value, o
+        self._slab_bytes = batch * self.rows * self.buf.element_size()
+
+    @property
+    def local(self) -> torch.Tensor:
+        return self.buf[self.rank]
+
+    def gather(self):
+        import ctypes
+        from . import lib as ggqlib
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.buf.device).cuda_stream)
+        row_bytes = self.rows * self.buf.element_size()
+        src = ctypes.c_void_p(self.local.data_ptr())
+        for p, base in self._peer_ptr.items():   # slot `rank` of peer p's buffer
+            dst = ctypes.c_void_p(base + self.rank * self._slab_bytes)
+            ggqlib.check(self.L.ggq_peer_write_2d(dst, row_bytes, src, row_bytes, row_bytes, self.batch, stream), "ggq_peer_write_2d")
+        torch.cuda.current_stream(self.buf.device).synchronize()
+        dist.barrier(group=self.group)
+        return None
+
+    def batch_major(self) -> torch.Tensor:
+        return unpermute_gathered(self.buf)
+
+    def close(self):
+        for p, base in list(self._peer_ptr.items()):
+            self.L.ggq_peer_close(base, self._peer_off[p])
+        self._peer_ptr.clear()
+
+
 def unpermute_gathered(buf: torch.Tensor) -> torch.Tensor:
     """[P, batch, rows] gather buffer -> [batch, P*rows]"""
     p, b, r = buf.shape

@@ -38,6 +38,10 @@ HIP_SYMBOLS = {
     "ggq_mul_mat_q_pretiled_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ggq_mul_mat_q_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ggq_mul_mat_vec_q_prequant": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "ggq_peer_export": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
+    "ggq_peer_import": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p)]),
+    "ggq_peer_close": (c_int, [c_void_p, c_int64]),
+    "ggq_peer_write_2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 }
 CPU_SYMBOLS = {
     "ggq_cpu_dequantize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int]),

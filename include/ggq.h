@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 2   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported */
+#define GGQ_ABI_VERSION 3   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_* */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -187,6 +187,19 @@ int ggq_cpu_dequantize_f32(const void* w, float* out, int type, int64_t m, int64
 int ggq_cpu_dequantize_f32_ex(const void* w, float* out, int type, int64_t m, int64_t n,
                               int nthreads, int simd);
 const char* ggq_cpu_simd_name(void);
+
+/* ---- peer-mapped output slabs (multi-GPU, one process per GPU; no reference counterpart: the reference has no
+ * multi-device code).  A rank exports the gather buffer it allocated as 64 opaque bytes + the byte offset of
+ * the pointer inside its allocation; the other ranks import it and may then pass the mapped pointer as the `y` / `dst` of
+ * any entry point above: the matmul's slab is written straight into the peer's buffer over xGMI (device-to-device stores),
+ * no collective and no staging copy.  ggq_peer_write_2d copies a [rows x row_bytes] slab with independent pitches on a
+ * stream.  Ordering across processes is the caller's (an event / barrier after the stream has drained).
+ * Needs dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0). */
+int ggq_peer_export(const void* dev_ptr, void* handle_out_64_bytes, int64_t* offset_out);
+int ggq_peer_import(const void* handle_64_bytes, int64_t offset, void** dev_ptr_out);
+int ggq_peer_close(void* dev_ptr, int64_t offset);
+int ggq_peer_write_2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t row_bytes,
+                      int64_t rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,45 @@
+"""worker of tests/test_peer_gather.py: RANK/WORLD_SIZE processes that all use cuda:0 (gloo group for the hand-off)"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ggml-libtorch_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from ggq import synth                       # noqa: E402
+from ggq.dist import PeerSlabGather, shard_rows   # noqa: E402
+from ggq.formats import GGMLType            # noqa: E402
+import util                                 # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t, batch, k, n_rows = GGMLType.Q4_K, 40, 1024, 64 * world
+    w = synth.random_weight(t, n_rows, k, seed=11)
+    x = torch.randn((batch, k), generator=torch.Generator().manual_seed(12)).half().cuda()
+    s, e = shard_rows(n_rows, world, rank)
+    pg = PeerSlabGather(batch, n_rows, torch.float16, x.device)
+    # the rank's slab, written by the matmul into its own slot (row pitch = rows of the slot)
+    y_local = util.gpu_mmq(w[s:e], x, t, e - s)
+    pg.local.copy_(y_local)
+    pg.gather()
+    full = util.gpu_mmq(w, x, t, n_rows)    # the one-GPU result: every slab is computed by the same kernels
+    ok = torch.equal(pg.batch_major(), full)
+    pg.close()
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    dist.destroy_process_group()
+    if not all(flags):
+        print(f"rank {rank}: gathered result differs: {flags}", flush=True)
+        sys.exit(1)
+    if rank == 0:
+        print("peer gather ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()
