@@ -290,6 +290,32 @@ def strong_scaling_config5(L, dev, world, rank, dist):
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 us = float(tt.item())
             entry[name] = {"us": round(us, 2)}
+        if world > 1 and os.environ.get("GGQ_BENCH_PEER") == "1":
+            # opt-in (never run on a multi-GPU node by this build: a fault here must not cost the default scaling run):
+            # the peer-mapped direct-write gather (ggq.dist.PeerSlabGather: HIP IPC, device-to-device stores over xGMI,
+            # host barrier) instead of the RCCL all-gather; wall clock around kernel + push + barrier
+            try:
+                from ggq.dist import PeerSlabGather
+                pg = PeerSlabGather(b, N5, torch.float16, dev)
+                def peer_step():
+                    if b == 1:
+                        rc = L.ggq_mul_mat_vec_q(vp(w5), vp(x), vp(pg.local), Q4_K, 1, K5, rows, vp(sc), cur_stream())
+                    else:
+                        rc = L.ggq_mul_mat_q_ld(vp(w5), vp(x), vp(pg.local), Q4_K, 1, b, K5, rows, rows, vp(sc), cur_stream())
+                    assert rc == 0, rc
+                    pg.gather()
+                for _ in range(3):
+                    peer_step()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    peer_step()
+                us = (time.perf_counter() - t0) * 1e6 / 20
+                tt = torch.tensor([us], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                entry["end_to_end_peer_write"] = {"us": round(float(tt.item()), 2), "timing": "wall clock, kernel + peer writes + stream drain + host barrier"}
+                pg.close()
+            except Exception as ex:  # pragma: no cover
+                entry["end_to_end_peer_write"] = {"error": repr(ex)[:300]}
         nbytes = algo_bytes_matmul(Q4_K, N5, K5, b)
         entry["end_to_end"]["GB/s_whole_job"] = round(nbytes / (entry["end_to_end"]["us"] * 1e-6) / 1e9, 1)
         entry["message_bytes_per_rank"] = b * rows * 2
