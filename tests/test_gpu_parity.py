@@ -72,7 +72,8 @@ def test_dequantize_empty_and_errors():
     assert L.ggq_dequantize_f16(None, None, 2, 1, 32, None) == -4   # null pointers
 
 
-@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K], ids=lambda t: t.name)
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K, GGMLType.Q3_K, GGMLType.Q6_K, GGMLType.IQ4_XS],
+                         ids=lambda t: t.name)
 def test_dequantize_full_size(oracle, t):
     """BASELINE config 2 shape: 11008 x 4096 (45 M elements), checked bit-exact in full."""
     n_rows, k = 11008, 4096
