@@ -116,11 +116,54 @@ GGQ_AVX2 void deq_q8_0_avx2(const uint8_t* w, float* y, int64_t b0, int64_t b1) 
   }
 }
 
+// ---- AVX-512 (F + BW + VL): 16 outputs per instruction, the same operations per element (integer subtract, exact
+//      int -> float conversion, one multiply, one add: no fused multiply-add), so the results stay bit-identical ----
+#define GGQ_AVX512 __attribute__((target("avx512f,avx512bw,avx512vl")))
+template <bool SIGNED, bool HAS_M>
+GGQ_AVX512 inline void store16_512(__m128i v, int offset, __m512 d, __m512 m, float* o) {
+  __m512i i = SIGNED ? _mm512_cvtepi8_epi32(v) : _mm512_cvtepu8_epi32(v);
+  i = _mm512_sub_epi32(i, _mm512_set1_epi32(offset));
+  __m512 f = _mm512_mul_ps(_mm512_cvtepi32_ps(i), d);
+  if (HAS_M) f = _mm512_add_ps(f, m);
+  _mm512_storeu_ps(o, f);
+}
+template <int OFFSET, bool HAS_M, bool HAS_QH, int BS>
+GGQ_AVX512 void deq_nibble_blocks_avx512(const uint8_t* w, float* y, int64_t b0, int64_t b1) {
+  constexpr int QS = 2 + (HAS_M ? 2 : 0) + (HAS_QH ? 4 : 0);
+  const __m128i low4 = _mm_set1_epi8(0x0F);
+  for (int64_t i = b0; i < b1; ++i) {
+    const uint8_t* b = w + i * BS;
+    const __m512 d = _mm512_set1_ps(h2f(rd16(b)));
+    const __m512 m = _mm512_set1_ps(HAS_M ? h2f(rd16(b + 2)) : 0.0f);
+    const __m128i q = _mm_loadu_si128((const __m128i*)(b + QS));
+    __m128i lo = _mm_and_si128(q, low4), hi = _mm_and_si128(_mm_srli_epi16(q, 4), low4);
+    if (HAS_QH) {   // bit e of qh -> 0x10 in byte e: one masked broadcast
+      const __m256i h = _mm256_maskz_set1_epi8((__mmask32)rd32(b + (HAS_M ? 4 : 2)), 0x10);
+      lo = _mm_or_si128(lo, _mm256_castsi256_si128(h));
+      hi = _mm_or_si128(hi, _mm256_extracti128_si256(h, 1));
+    }
+    store16_512<false, HAS_M>(lo, OFFSET, d, m, y + i * 32);
+    store16_512<false, HAS_M>(hi, OFFSET, d, m, y + i * 32 + 16);
+  }
+}
+GGQ_AVX512 void deq_q8_0_avx512(const uint8_t* w, float* y, int64_t b0, int64_t b1) {
+  for (int64_t i = b0; i < b1; ++i) {
+    const uint8_t* b = w + i * 34;
+    const __m512 d = _mm512_set1_ps(h2f(rd16(b))), z = _mm512_setzero_ps();
+    store16_512<true, false>(_mm_loadu_si128((const __m128i*)(b + 2)), 0, d, z, y + i * 32);
+    store16_512<true, false>(_mm_loadu_si128((const __m128i*)(b + 18)), 0, d, z, y + i * 32 + 16);
+  }
+}
+
 bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+bool have_avx512() {
+  static const bool v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+  return v;
+}
 
 }  // namespace
 
-extern "C" const char* ggq_cpu_simd_name(void) { return have_avx2() ? "avx2" : "scalar"; }
+extern "C" const char* ggq_cpu_simd_name(void) { return have_avx512() ? "avx512" : have_avx2() ? "avx2" : "scalar"; }
 
 extern "C" int ggq_cpu_dequantize_f32(const void* w, float* out, int type, int64_t m, int64_t n, int nthreads) {
   return ggq_cpu_dequantize_f32_ex(w, out, type, m, n, nthreads, 1);
@@ -130,15 +173,19 @@ extern "C" int ggq_cpu_dequantize_f32_ex(const void* w, float* out, int type, in
                                          int nthreads, int simd) {
   if (m < 0 || n < 0) return GGQ_ERR_ARG;
   range_fn fn = nullptr;
+  // simd: 0 scalar, 2 at most AVX2, any other value the widest unit of the host
+  const bool v5 = simd != 0 && simd != 2 && have_avx512();
   const bool v = simd != 0 && have_avx2();
+#define GGQ_PICK(A512, A2, SC) (v5 ? (range_fn)A512 : v ? (range_fn)A2 : (range_fn)SC)
   switch (type) {  // the five formats of ggml-cpu/custom_ops.cpp:16-34
-    case GGQ_TYPE_Q4_0: fn = v ? deq_nibble_blocks_avx2<8, false, false, 18> : deq_nibble_blocks<8, false, false, 18>; break;
-    case GGQ_TYPE_Q4_1: fn = v ? deq_nibble_blocks_avx2<0, true, false, 20> : deq_nibble_blocks<0, true, false, 20>; break;
-    case GGQ_TYPE_Q5_0: fn = v ? deq_nibble_blocks_avx2<16, false, true, 22> : deq_nibble_blocks<16, false, true, 22>; break;
-    case GGQ_TYPE_Q5_1: fn = v ? deq_nibble_blocks_avx2<0, true, true, 24> : deq_nibble_blocks<0, true, true, 24>; break;
-    case GGQ_TYPE_Q8_0: fn = v ? deq_q8_0_avx2 : deq_q8_0; break;
+    case GGQ_TYPE_Q4_0: fn = GGQ_PICK((deq_nibble_blocks_avx512<8, false, false, 18>), (deq_nibble_blocks_avx2<8, false, false, 18>), (deq_nibble_blocks<8, false, false, 18>)); break;
+    case GGQ_TYPE_Q4_1: fn = GGQ_PICK((deq_nibble_blocks_avx512<0, true, false, 20>), (deq_nibble_blocks_avx2<0, true, false, 20>), (deq_nibble_blocks<0, true, false, 20>)); break;
+    case GGQ_TYPE_Q5_0: fn = GGQ_PICK((deq_nibble_blocks_avx512<16, false, true, 22>), (deq_nibble_blocks_avx2<16, false, true, 22>), (deq_nibble_blocks<16, false, true, 22>)); break;
+    case GGQ_TYPE_Q5_1: fn = GGQ_PICK((deq_nibble_blocks_avx512<0, true, true, 24>), (deq_nibble_blocks_avx2<0, true, true, 24>), (deq_nibble_blocks<0, true, true, 24>)); break;
+    case GGQ_TYPE_Q8_0: fn = GGQ_PICK(deq_q8_0_avx512, deq_q8_0_avx2, deq_q8_0); break;
     default: return GGQ_ERR_TYPE;
   }
+#undef GGQ_PICK
   const int64_t k = m * n;
   if (k % 32) return GGQ_ERR_SHAPE;
   if (k == 0) return GGQ_OK;

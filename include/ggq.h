@@ -181,9 +181,10 @@ int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, 
  * fp32 output, host memory. nthreads <= 1 reproduces the reference's single-thread loop. */
 int ggq_cpu_dequantize_f32(const void* w, float* out, int type, int64_t m, int64_t n,
                            int nthreads);
-/* the same with the vector path selectable: simd = 0 forces the scalar loops (the reference's form), non-zero uses
- * the widest unit the host has (AVX2: eight elements per instruction, bit-identical results).
- * ggq_cpu_simd_name(): "avx2" or "scalar". */
+/* the same with the vector path selectable: simd = 0 forces the scalar loops (the reference's form), 2 at most AVX2,
+ * any other value the widest unit the host has (AVX-512 F+BW+VL: sixteen elements per instruction; AVX2: eight) —
+ * integer subtract, exact int -> float conversion, one multiply, one add per element in every path: bit-identical results.
+ * ggq_cpu_simd_name(): "avx512", "avx2" or "scalar". */
 int ggq_cpu_dequantize_f32_ex(const void* w, float* out, int type, int64_t m, int64_t n,
                               int nthreads, int simd);
 const char* ggq_cpu_simd_name(void);

@@ -57,7 +57,7 @@ def test_threaded_equals_single_thread(quant_type):
 
 @pytest.mark.parametrize("quant_type", QUANT_TYPES, ids=lambda t: t.name)
 def test_vector_path_equals_scalar_path_bit_for_bit(quant_type):
-    """ggq_cpu_dequantize_f32_ex(simd=1) (AVX2 where the host has it) vs simd=0 (the reference's scalar loops) on random
+    """ggq_cpu_dequantize_f32_ex(simd=1 / 2) (AVX-512 / AVX2 where the host has them) vs simd=0 (the reference's scalar loops) on random
     and edge blocks, incl. NaN / inf / subnormal scales: identical bit patterns, so the golden test above pins both."""
     L = ggqlib.cpu()
     blocks = np.concatenate([synth.random_blocks(quant_type, 1500, seed=2), synth.edge_blocks(quant_type)])
@@ -66,9 +66,12 @@ def test_vector_path_equals_scalar_path_bit_for_bit(quant_type):
     b = np.empty_like(a)
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
     assert L.ggq_cpu_dequantize_f32_ex(p(blocks), p(a), int(quant_type), 1, nb * 32, 1, 0) == 0
-    assert L.ggq_cpu_dequantize_f32_ex(p(blocks), p(b), int(quant_type), 1, nb * 32, 3, 1) == 0
+    assert L.ggq_cpu_dequantize_f32_ex(p(blocks), p(b), int(quant_type), 1, nb * 32, 3, 1) == 0     # widest unit (AVX-512 / AVX2)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert L.ggq_cpu_simd_name() in (b"avx2", b"scalar")
+    b[:] = 0
+    assert L.ggq_cpu_dequantize_f32_ex(p(blocks), p(b), int(quant_type), 1, nb * 32, 1, 2) == 0     # at most AVX2
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert L.ggq_cpu_simd_name() in (b"avx512", b"avx2", b"scalar")
 
 
 def test_errors(ops):
