@@ -65,7 +65,8 @@ template <int T> struct UnitDot;
 // formats whose UnitDot has the load / dot split (Raw, load(), dot())
 template <int T> struct UnitHasPre {
   static constexpr bool value = T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 || T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1 ||
-                                T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_K;   // (Q5_K: three 16-byte loads per unit x 3 rows spill at 128 VGPRs)
+                                T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_IQ4_NL || T == GGQ_TYPE_IQ4_XS;
+  // (Q5_K: three 16-byte loads per unit x 3 rows spill at 128 VGPRs)
 };
 
 template <> struct UnitDot<GGQ_TYPE_Q4_0> {  // vecdotq.cuh:45-65, 347-363
@@ -323,24 +324,34 @@ template <> struct UnitDot<GGQ_TYPE_Q6_K> {  // vecdotq.cuh:327-345, 587-605
 // of one 32-element (sub-)block: low nibbles x q8[0..15], high nibbles x q8[16..31]; float part d · (ls - 32) · d8.
 template <> struct UnitDot<GGQ_TYPE_IQ4_NL> {
   static constexpr int UPB = 1;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { uint32_t d; u32x4_a2 q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 18;
-    const u32x4_a2 q = ld_u32x4(b + off::IQ4_NL_QS);
+    return Raw{ld_u16(b), ld_u32x4(b + off::IQ4_NL_QS)};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const u32x4_a2& q = R.q;
     const v4i a0 = lds_ld16(A.xq + 32 * u), a1 = lds_ld16(A.xq + 32 * u + 16);
     uint32_t lo[4], hi[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { lo[i] = iq4nl_lookup4(q.v[i] & 0x0F0F0F0F); hi[i] = iq4nl_lookup4((q.v[i] >> 4) & 0x0F0F0F0F); }
-    const float d = bits_h_f32(ld_u16(b)) * A.xd[u];
+    const float d = bits_h_f32(R.d) * A.xd[u];
     return d * (float)(dot16(lo, a0) + dot16(hi, a1));
   }
 };
 template <> struct UnitDot<GGQ_TYPE_IQ4_XS> {
   static constexpr int UPB = 8;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
-    const int ib = u >> 3, ib32 = u & 7, g = u;   // group g = 8 ib + ib32
-    const uint8_t* b = row + (int64_t)ib * 136;
-    const u32x2_a2 hd = ld_u32x2(b);
-    const u32x4_a2 q = ld_u32x4(b + off::IQ4_XS_QS + 16 * ib32);
+  struct Raw { u32x2_a2 hd; u32x4_a2 q; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
+    const uint8_t* b = row + (int64_t)(u >> 3) * 136;
+    return Raw{ld_u32x2(b), ld_u32x4(b + off::IQ4_XS_QS + 16 * (u & 7))};
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const int ib32 = u & 7, g = u;   // group g = 8 ib + ib32
+    const u32x2_a2& hd = R.hd;
+    const u32x4_a2& q = R.q;
     const v4i a0 = lds_ld16(A.xq + 32 * g), a1 = lds_ld16(A.xq + 32 * g + 16);
     uint32_t lo[4], hi[4];
 #pragma unroll
