@@ -65,7 +65,7 @@ template <int T> struct UnitDot;
 // formats whose UnitDot has the load / dot split (Raw, load(), dot())
 template <int T> struct UnitHasPre {
   static constexpr bool value = T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 || T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1 ||
-                                T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_IQ4_NL || T == GGQ_TYPE_IQ4_XS;
+                                T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q6_K || T == GGQ_TYPE_IQ4_NL || T == GGQ_TYPE_IQ4_XS;
   // (Q5_K: three 16-byte loads per unit x 3 rows spill at 128 VGPRs)
 };
 
@@ -296,18 +296,30 @@ template <> struct UnitDot<GGQ_TYPE_Q5_K> {  // vecdotq.cuh:295-323, 539-585
 // elements of group 4ip + c/2, high nibbles: 16 elements of group 4ip + 2 + c/2, positions 16(c&1)..
 template <> struct UnitDot<GGQ_TYPE_Q6_K> {  // vecdotq.cuh:327-345, 587-605
   static constexpr int UPB = 8;
-  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+  struct Raw { u32x4_a2 ql, qh; uint32_t d; int sc[2]; };
+  static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const int ib = u >> 3, ip = (u >> 2) & 1, c = u & 3;
     const uint8_t* b = row + (int64_t)ib * 210;
-    const u32x4_a2 ql = ld_u32x4(b + off::Q6_K_QL + 64 * ip + 16 * c);
-    const u32x4_a2 qh = ld_u32x4(b + off::Q6_K_QH + 32 * ip + 16 * (c & 1));
-    const float d = bits_h_f32(ld_u16(b + off::Q6_K_D));
+    Raw R;
+    R.ql = ld_u32x4(b + off::Q6_K_QL + 64 * ip + 16 * c);
+    R.qh = ld_u32x4(b + off::Q6_K_QH + 32 * ip + 16 * (c & 1));
+    R.d = ld_u16(b + off::Q6_K_D);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R.sc[i] = (int8_t)b[off::Q6_K_SC + 8 * ip + 2 * ((c >> 1) + 2 * i) + (c & 1)];
+    return R;
+  }
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
+  static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
+    const int ib = u >> 3, ip = (u >> 2) & 1, c = u & 3;
+    const u32x4_a2& ql = R.ql;
+    const u32x4_a2& qh = R.qh;
+    const float d = bits_h_f32(R.d);
     float sumf = 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int j = (c >> 1) + 2 * i;          // 32-element group inside the half
       const int g = 8 * ib + 4 * ip + j;
-      const int sc = (int8_t)b[off::Q6_K_SC + 8 * ip + 2 * j + (c & 1)];
+      const int sc = R.sc[i];
       const v4i a = lds_ld16(A.xq + 32 * g + 16 * (c & 1));
       uint32_t v[4];
 #pragma unroll
