@@ -23,13 +23,13 @@ INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 ARCH = "gfx950"
 EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX")
 
-HIP_SOURCES = ["dequant", "quantize", "mmvq", "mmq", "peer"]
+HIP_SOURCES = ["dequant", "quantize", "mmvq", "mmq", "mmq_t16", "peer"]
 TRAITS_SRC = os.path.join(CSRC, "core", "traits.cpp")
 # No implicit fused-multiply-add contraction anywhere: the fp16 dequantise sequence and the Q8_1
 # quantiser must round after every operation exactly like the reference's intrinsics, and in the
 # matmul kernels contraction made the rounding of an output depend on which accumulator register
 # (i.e. which tile row) it landed in.  FMAs are written explicitly (__builtin_fmaf) where wanted.
-NO_CONTRACT = {"dequant", "quantize", "mmvq", "mmq"}
+NO_CONTRACT = {"dequant", "quantize", "mmvq", "mmq", "mmq_t16"}
 
 
 def _hipcc():

@@ -1,0 +1,384 @@
+// mmq_t16.hip — quantised GEMM for the HBM-bound batches (5 .. 64 tokens): 16-row x 16-token MFMA tiles, a wave's whole
+// share of the weight matrix requested before anything is waited for.  gfx950 only.
+//
+// Same contract as mmq.hip (mul_mat_q, HK/ggml/mmq.cuh:1917-1986, "MMQ canon" of SURVEY §8a: exact int8 contraction per
+// 32-element group, the float factors of the reference's tensor-core bodies, fp32 accumulation order ours); what differs is
+// the regime it is built for.  Between the GEMV and the 32-token MFMA tile the matmul is bound by how fast the weight
+// matrix streams out of HBM, i.e. by bytes in flight and by what the texture addresser pays per 128-byte line a wave-level
+// load touches (measured with the per-wave stamps of scripts/stamps_t16.py: the first version of this kernel
+// spent 2.5 - 5 us just ISSUING its requests, because 16 rows x 64 bytes per load is 16 lines per KB and the activation
+// fragments cost as many lines again).  So:
+//   * workgroup = one 16-row weight tile x KS K-slices (one wave each); a wave's slice is at most MAXU 256-element units and
+//     the first thing a wave does is request all of it by LDS-DMA (global_load_lds_dwordx4: no destination registers, so
+//     the whole slice is in flight whatever the register budget) in ROW-MAJOR LINEAR order — consecutive lanes = consecutive
+//     16-byte chunks of a row's slice, ~9.5 lines per KB, block headers included — into a wave-private LDS image
+//     [16 rows][slice bytes].  The K loop is a rolled loop over units that reads its MFMA operands from that image.
+//   * v_mfma_i32_16x16x64_i8, A = activations (rows = tokens), B = weights (columns = 16 weight rows): lane (row j = lane & 15,
+//     K-chunk c = lane >> 4) holds bytes 16 c .. 16 c + 15 of a 64-byte half of the unit's nibble field: low nibbles of one
+//     32-group half and high nibbles of the next group's half; lanes c < 2 belong to one group pair, lanes c >= 2 to the next.
+//       batch <= 8  ("M8"): the 16 token rows of A are tokens 0-7 twice — rows 0-7 carry the activations only in the K-chunks
+//         of the first pair, rows 8-15 only in those of the second (the other chunks read as zeros: buffer loads past the
+//         descriptor's range, no memory traffic) — so ONE MFMA yields two groups' sums (rows 0-7 / 8-15), the weight
+//         operand needs no masking, and a lane scales 4 results per MFMA instead of 8 useful ones out of 16.
+//       batch 9-16 and NTT > 1: one MFMA per group with the other pair's lanes of B zeroed.
+//   * output: lane = weight row, register r = token 4 c + r (M8: token 4 (c & 1) + r, group pair c >> 1).  The row scale
+//     d * sc is a lane scalar decoded from the row's header; the token scales half2(d8, s8) come from a wave-private LDS copy
+//     of the slice's scale table (broadcast ds_read_b128), applied with v_fma_mix_f32 (reads the fp16 d8 in place).
+//   * Q4_K / Q5_K min term  sum_g s8[token][g] * -(dmin m_g)[row]: K = 4 per unit half -> v_mfma_f32_16x16x4_f32 straight
+//     into the accumulators (exact fp32 FMAs in a fixed order, off the vector ALU).
+//   * activations: the 16- / 8-token-tile fragment layouts of quantize.hip (LAYOUT 3 / 4), one coalesced load per MFMA
+//     operand, read from L2 by every wave, requested one unit ahead.
+//   * K-slice partial sums meet once in LDS, summed in slice order (fixed order: bit-reproducible, independent of the
+//     wave that adds).
+#include "ggq_common.h"
+#include "mmq_unpack.h"
+
+#ifndef GGQ_T16_STAMP
+#define GGQ_T16_STAMP 0   // 1: per-wave timestamps (scripts/stamps_t16.py); 0 in every shipped build
+#endif
+#if GGQ_T16_STAMP
+__device__ unsigned long long g_t16_stamps[4096 * 16 * 8];
+extern "C" int ggq_debug_read_t16_stamps(void* dst, long long n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_t16_stamps), n * 8);
+}
+#define T16_STAMP(i)                                                                                          \
+  do {                                                                                                        \
+    if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0) g_t16_stamps[(blockIdx.x * 16 + ks) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define T16_STAMP(i) do {} while (0)
+#endif
+
+namespace ggq {
+
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+struct Epi16 { int kind; const void* aux; };
+template <int DT>
+__device__ __forceinline__ float t16_epilogue(float v, int epi, const void* aux, int64_t yi, int row) {
+  if (epi == GGQ_EPI_BIAS) return v + Elem<DT>::ld(aux, row);
+  if (epi == GGQ_EPI_SILU_MUL) {
+    const float g = Elem<DT>::ld(aux, yi);
+    return v * (g / (1.0f + expf(-g)));
+  }
+  return v;
+}
+
+template <int T> struct T16Fmt {
+  static_assert(T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K, "format");
+  static constexpr int UB = 256 / Fmt<T>::QK * Fmt<T>::BS;   // bytes of one 256-element unit of a weight row
+  static constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : off::Q5_K_QS;
+  static constexpr bool has_qh = T == GGQ_TYPE_Q5_K;
+};
+
+// wave-private LDS (bytes): W [16 rows][MAXU units] raw bytes | TAB scale tables
+template <int T, bool M8, int NTT, int MAXU> struct T16Lds {
+  static constexpr int SB = MAXU * T16Fmt<T>::UB;          // slice bytes of one row
+  static constexpr int NI = 16 * SB / 1024;                // DMA instructions (1 KB each) of the weight image
+  static_assert(16 * SB % 1024 == 0, "whole DMA instructions");
+  static constexpr int TT = M8 ? 256 : 512;                // scale table of one (unit, token tile)
+  static constexpr int W = 0;
+  static constexpr int TAB = 16 * SB;
+  static constexpr int WAVE = TAB + NTT * MAXU * TT;
+  static constexpr int TILE = M8 ? 2304 : 4608;            // activation tile of one (unit, token tile)
+  static constexpr int FRAG = M8 ? 512 : 1024;
+};
+
+typedef const __attribute__((address_space(1))) void* t16_gptr;
+typedef __attribute__((address_space(3))) void* t16_lptr;
+
+// M8: at most 8 tokens (NTT = 1).  NTT = 16-token tiles per workgroup.  MAXU = units of a wave's slice held in LDS.
+template <int T, int DT, bool M8, int NTT, int MAXU, int MAXKS>
+__global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
+                                                             void* __restrict__ y, int n_units, int ups, int n_rows, int batch,
+                                                             int64_t ldy, int n_tt, int epi, const void* __restrict__ aux) {
+  using F = T16Fmt<T>;
+  using L = T16Lds<T, M8, NTT, MAXU>;
+  static_assert(!M8 || NTT == 1, "M8: one token tile");
+  constexpr int UB = F::UB, SB = L::SB;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [wave] T16Lds ; aliased by the K-slice reduction
+  const int lane = threadIdx.x & 63;
+  const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KS = blockDim.x >> 6;
+  const int j = lane & 15, c = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int tt0 = blockIdx.y * NTT;
+  const int u0 = ks * ups, u1 = min(n_units, u0 + ups);   // the launcher makes every slice non-empty
+  const uint32_t row_bytes = (uint32_t)n_units * UB;
+  const uint8_t* wtile = w + (int64_t)n0 * row_bytes;
+  const int rmax = min(15, n_rows - 1 - n0);               // rows past the tensor repeat the last one (never stored)
+  uint8_t* wl = lds + ks * L::WAVE;
+  T16_STAMP(0);
+
+  // activations: one descriptor over the scratch, scalar tile offsets, the lane's 16 bytes of a fragment
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q8, 0, (int)0x7FFFFFFF, 0x00020000);
+  auto tile_off = [&](int u, int jj) { return (uint32_t)((u * n_tt + min(tt0 + jj, n_tt - 1)) * L::TILE); };
+  // M8: lane (A row j, K-chunk c) holds token j & 7 in the chunks of its row half's group pair and ZERO in the others
+  // (offset beyond the descriptor's range: the load returns 0 and touches no memory)
+  const uint32_t frag_voff = !M8 ? (uint32_t)lane * 16 : ((j < 8) == (c < 2)) ? (uint32_t)(c * 8 + (j & 7)) * 16 : 0x80000000u;
+  auto ld_frag = [&](uint32_t toff, int f) {
+    const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)frag_voff, (int)(toff + f * L::FRAG), 0);
+    return v4i{(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
+  };
+  // fragments of one unit (two halves x NTT token tiles x {low, high} nibble operands), requested one unit ahead
+  struct Frags { v4i a[2][NTT][2]; };
+  auto request_frags = [&](Frags& Fr, int u) {
+    const int ue = min(u, u1 - 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int jj = 0; jj < NTT; ++jj) {
+        const uint32_t toff = tile_off(ue, jj);
+        Fr.a[q][jj][0] = ld_frag(toff, 2 * q);
+        Fr.a[q][jj][1] = ld_frag(toff, 2 * q + 1);
+      }
+  };
+  // ---- everything the wave reads of units [ub, ub + MAXU) is requested here by LDS-DMA: scale tables, then the weight
+  //      image in row-major linear order (chunk n = 64 i + lane of instruction i: row n / CPR, 16-byte column n % CPR) ----
+  auto request_round = [&](int ub) {
+    if constexpr (M8) {   // 256 bytes per unit: lane = (unit lane >> 4, 16 bytes lane & 15)
+      const uint32_t o = tile_off(min(ub + (lane >> 4), u1 - 1), 0) + 2048 + (lane & 15) * 16;
+      __builtin_amdgcn_global_load_lds((t16_gptr)(q8 + o), (t16_lptr)(wl + L::TAB), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < NTT; ++jj)
+#pragma unroll
+        for (int sp = 0; sp < MAXU / 2; ++sp) {   // 512 bytes per (unit, token tile): lanes 0-31 unit 2 sp, lanes 32-63 unit 2 sp + 1
+          const uint32_t o = tile_off(min(ub + 2 * sp + (lane >> 5), u1 - 1), jj) + 4096 + (lane & 31) * 16;
+          __builtin_amdgcn_global_load_lds((t16_gptr)(q8 + o), (t16_lptr)(wl + L::TAB + (jj * MAXU + 2 * sp) * 512), 16, 0, 0);
+        }
+    }
+    constexpr int CPR = SB / 16, CPU = UB / 16;   // 16-byte chunks per row slice / per unit
+#pragma unroll
+    for (int i = 0; i < L::NI; ++i) {
+      const int n = 64 * i + lane;
+      const int row = n / CPR, col = n - row * CPR;
+      const int su = col / CPU, within = col - su * CPU;
+      const uint8_t* src = wtile + ((uint32_t)min(row, rmax) * row_bytes + (uint32_t)min(ub + su, u1 - 1) * UB + 16 * within);
+      __builtin_amdgcn_global_load_lds((t16_gptr)src, (t16_lptr)(wl + L::W + i * 1024), 16, 0, 0);
+    }
+  };
+
+  v4f acc[NTT];
+#pragma unroll
+  for (int jj = 0; jj < NTT; ++jj) acc[jj] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  const uint32_t m_lo = c < 2 ? 0x0F0F0F0Fu : 0u, m_hi = c < 2 ? 0u : 0x0F0F0F0Fu;   // lanes of the unit half's first / second group pair
+  const int sel = c >> 1;   // the lane's group pair within a unit half
+
+  // one unit: slot s of the round, fragments Fr
+  auto compute_unit = [&](int s, const Frags& Fr) {
+    const uint8_t* blk = wl + L::W + j * SB + s * UB;   // row j's block of this unit
+    // ---- row scales of the unit's 8 groups: d * sc_g and -(dmin * m_g)  (get_scale_min_k4, dequantize.cuh:154-161) ----
+    const v4u_t hd = *(const v4u_t*)blk;   // {d | dmin << 16, scales[0..3], scales[4..7], scales[8..11]}
+    const uint32_t s0 = hd[1], s1 = hd[2], s2 = hd[3];
+    const uint32_t sc4[2] = {s0 & 0x3F3F3F3Fu, (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u)};
+    const uint32_t mn4[2] = {s1 & 0x3F3F3F3Fu, ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u)};
+    const float dall = bits_h_f32(hd[0] & 0xFFFF), dmin = bits_h_f32(hd[0] >> 16);
+    v4u_t qh = {0, 0, 0, 0};
+    if constexpr (F::has_qh) qh = *(const v4u_t*)(blk + off::Q5_K_QH + 16 * (c & 1));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const v4u_t raw = *(const v4u_t*)(blk + F::QS + 64 * q + 16 * c);
+      v4i b_lo, b_hi;   // the lane's 16 elements of group 4q + 2 sel (low nibbles) and 4q + 2 sel + 1 (high nibbles)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t lo = raw[i] & 0x0F0F0F0Fu, hi = (raw[i] >> 4) & 0x0F0F0F0Fu;
+        if constexpr (F::has_qh) {   // high bit of element b of group g: bit g of qh[b]
+          const uint32_t hsel = qh[i] >> (4 * q + 2 * sel);
+          lo |= (hsel & 0x01010101u) << 4;
+          hi |= ((hsel >> 1) & 0x01010101u) << 4;
+        }
+        b_lo[i] = (int)lo; b_hi[i] = (int)hi;
+      }
+      // min term, B operand of the f32 MFMA below: lane (row j, k = c) holds -(dmin * m) of group 4 q + c
+      const float mwc = -(dmin * (float)((mn4[q] >> (8 * c)) & 0xFF));
+      const v4i zero = {0, 0, 0, 0};
+      if constexpr (M8) {
+        const float dw_lo = dall * (float)((sc4[q] >> (16 * sel)) & 0xFF), dw_hi = dall * (float)((sc4[q] >> (16 * sel + 8)) & 0xFF);
+        const v4i C_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][0][0], b_lo, zero, 0, 0, 0);
+        const v4i C_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][0][1], b_hi, zero, 0, 0, 0);
+        const uint8_t* tq = wl + L::TAB + s * 256 + q * 128;   // [token quad][group][token] half2(d8, s8)
+        const uint32_t sw = *(const uint32_t*)(tq + ((j >> 2) & 1) * 64 + c * 16 + (j & 3) * 4);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < 8 ? bits_h_f32(sw >> 16) : 0.0f, mwc, acc[0], 0, 0, 0);
+        const v4u_t ds_lo = *(const v4u_t*)(tq + (c & 1) * 64 + (2 * sel) * 16), ds_hi = *(const v4u_t*)(tq + (c & 1) * 64 + (2 * sel + 1) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // float(C) * d8 rounded once (v_fma_mix_f32 reads the fp16 d8 in place), then the row scale (mmq.cuh:1274-1363 factors)
+          float t0, t1;
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t0) : "v"((float)C_lo[r]), "v"(ds_lo[r]));
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t1) : "v"((float)C_hi[r]), "v"(ds_hi[r]));
+          acc[0][r] = __builtin_fmaf(t0, dw_lo, acc[0][r]);
+          acc[0][r] = __builtin_fmaf(t1, dw_hi, acc[0][r]);
+        }
+      } else {
+        v4i b_a, b_b, b_c, b_d;   // group 4q (low nibbles, lanes c < 2), 4q+1 (high, c < 2), 4q+2 (low, c >= 2), 4q+3 (high, c >= 2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          b_a[i] = c < 2 ? b_lo[i] : 0; b_b[i] = c < 2 ? b_hi[i] : 0;
+          b_c[i] = c < 2 ? 0 : b_lo[i]; b_d[i] = c < 2 ? 0 : b_hi[i];
+        }
+        float dw[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dw[g] = dall * (float)((sc4[q] >> (8 * g)) & 0xFF);
+#pragma unroll
+        for (int jj = 0; jj < NTT; ++jj) {
+          v4i C[4];
+          C[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][0], b_a, zero, 0, 0, 0);
+          C[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][1], b_b, zero, 0, 0, 0);
+          C[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][0], b_c, zero, 0, 0, 0);
+          C[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][1], b_d, zero, 0, 0, 0);
+          const uint8_t* tq = wl + L::TAB + (jj * MAXU + s) * 512 + q * 256;   // [token quad][group][token] half2(d8, s8)
+          const uint32_t sw = *(const uint32_t*)(tq + (j >> 2) * 64 + c * 16 + (j & 3) * 4);
+          acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(bits_h_f32(sw >> 16), mwc, acc[jj], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const v4u_t ds = *(const v4u_t*)(tq + c * 64 + g * 16);   // tokens 4c .. 4c+3, group 4q + g
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float t;
+              asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t) : "v"((float)C[g][r]), "v"(ds[r]));
+              acc[jj][r] = __builtin_fmaf(t, dw[g], acc[jj][r]);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  Frags FA, FB;
+  request_frags(FA, u0);
+  request_frags(FB, u0 + 1);
+  for (int ub = u0; ub < u1; ub += MAXU) {
+    request_round(ub);   // (slices longer than MAXU units: the previous round's LDS reads have all returned — their results were used)
+    T16_STAMP(1);
+    // vmcnt counts loads and LDS-DMA together in issue order: everything requested so far has landed after this wait.
+    // (A counted wait per unit would need the image in unit-major order, which costs 1.7x the cache lines per KB.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), through the builtin so that hipcc's own wait insertion knows
+    __builtin_amdgcn_wave_barrier();
+    T16_STAMP(2);
+    const int ns = min(MAXU, u1 - ub);
+#pragma unroll 1
+    for (int s = 0; s < ns; s += 2) {
+      compute_unit(s, FA);
+      if (s == 0) T16_STAMP(3);
+      request_frags(FA, ub + s + 2);
+      if (s + 1 < ns) compute_unit(s + 1, FB);
+      request_frags(FB, ub + s + 3);
+    }
+  }
+
+  T16_STAMP(4);
+  // ---- K-slice reduction: sums in slice order, the (token tile, register) pairs dealt round-robin to the waves ----
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the last (unused) fragment prefetch
+  __syncthreads();
+  float* red = (float*)lds;   // [K-slice][NTT][4][64]
+#pragma unroll
+  for (int jj = 0; jj < NTT; ++jj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((ks * NTT + jj) * 4 + r) * 64 + lane] = acc[jj][r];
+  __syncthreads();
+  T16_STAMP(5);
+  const int row = n0 + j;
+  for (int p = ks; p < NTT * 4; p += KS) {
+    const int jj = p >> 2, r = p & 3;
+    float v = 0.0f;
+    int t;
+    if constexpr (M8) {   // lanes 0-31: token 4 c + r; its second group pair's partial sums sit 32 lanes up
+      const int l2 = lane & 31;
+      v = red[((0 * NTT + jj) * 4 + r) * 64 + l2] + red[((0 * NTT + jj) * 4 + r) * 64 + l2 + 32];
+      for (int sl = 1; sl < KS; ++sl) v += red[((sl * NTT + jj) * 4 + r) * 64 + l2] + red[((sl * NTT + jj) * 4 + r) * 64 + l2 + 32];
+      t = lane < 32 ? 4 * c + r : batch;
+    } else {
+      v = red[((0 * NTT + jj) * 4 + r) * 64 + lane];
+      for (int sl = 1; sl < KS; ++sl) v += red[((sl * NTT + jj) * 4 + r) * 64 + lane];
+      t = 16 * (tt0 + jj) + 4 * c + r;
+    }
+    if (t < batch && row < n_rows) {
+      const int64_t yi = (int64_t)t * ldy + row;
+      Elem<DT>::st(y, yi, t16_epilogue<DT>(v, epi, aux, yi, row));
+    }
+  }
+  T16_STAMP(6);
+}
+
+template <int T, int DT, bool M8, int NTT>
+static int launch_t16(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
+                      Epi16 ep) {
+  constexpr int MAXU = 4, MAXKS = 12;
+  using L = T16Lds<T, M8, NTT, MAXU>;
+  const int64_t n_units = k / 256;
+  const int64_t n_tt = M8 ? 1 : (batch + 15) / 16;
+  // K-slices: MAXU units per wave while that needs at most MAXKS waves (K <= 12288), longer slices (several LDS rounds) beyond
+  constexpr size_t red = (size_t)NTT * 4 * 64 * 4;
+  constexpr size_t wave = (size_t)L::WAVE > red ? (size_t)L::WAVE : red;
+  constexpr int64_t LDS_KS = (160 * 1024) / wave;   // waves whose LDS areas fit one CU
+  int64_t ks = (n_units + MAXU - 1) / MAXU;
+  if (ks > MAXKS) ks = MAXKS;
+  if (ks > LDS_KS) ks = LDS_KS;
+  const int64_t ups = (n_units + ks - 1) / ks;
+  ks = (n_units + ups - 1) / ups;   // no empty slice
+  const size_t lds = (size_t)ks * wave;
+  const int64_t gy = (n_tt + NTT - 1) / NTT;
+  const int64_t gx = (n + 15) / 16;
+  if (gx > 0x7fffffffLL || gy > 65535) return GGQ_ERR_SHAPE;
+  if ((uint64_t)n_units * T16Fmt<T>::UB * 16 >= (1ull << 32)) return GGQ_ERR_SHAPE;   // 32-bit byte offsets inside a 16-row tile
+  auto kern = mmq_t16_kernel<T, DT, M8, NTT, MAXU, MAXKS>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GGQ_ERR_LAUNCH;
+  GGQ_HIP_PRE_LAUNCH();
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3((unsigned)(64 * ks)), lds, s, (const uint8_t*)w, (const uint8_t*)q8, y,
+                     (int)n_units, (int)ups, (int)n, (int)batch, ldy, (int)n_tt, ep.kind, ep.aux);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
+}
+
+template <int T, int DT>
+static int launch_t16_dt(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
+                         Epi16 ep) {
+  if (batch <= 8) return launch_t16<T, DT, true, 1>(w, q8, y, batch, k, n, ldy, s, ep);   // (the scratch layout follows the batch too: quantize.hip)
+  if (batch <= 16) return launch_t16<T, DT, false, 1>(w, q8, y, batch, k, n, ldy, s, ep);
+  return launch_t16<T, DT, false, 2>(w, q8, y, batch, k, n, ldy, s, ep);
+}
+
+template <int T>
+static int launch_t16_t(const void* w, const void* q8, void* y, int dt, int64_t batch, int64_t k, int64_t n, int64_t ldy,
+                        hipStream_t s, Epi16 ep) {
+  switch (dt) {
+    case GGQ_F32: return launch_t16_dt<T, GGQ_F32>(w, q8, y, batch, k, n, ldy, s, ep);
+    case GGQ_F16: return launch_t16_dt<T, GGQ_F16>(w, q8, y, batch, k, n, ldy, s, ep);
+    case GGQ_BF16: return launch_t16_dt<T, GGQ_BF16>(w, q8, y, batch, k, n, ldy, s, ep);
+    default: return GGQ_ERR_DTYPE;
+  }
+}
+
+}  // namespace ggq
+
+extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
+  // 32-bit byte offsets into the activation scratch and into a weight row
+  if (!ggq_mmq_t16_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
+  if ((uint64_t)ggq_mmq_scratch_bytes(batch, k) >= (1ull << 31)) return 0;
+  return 1;
+}
+
+extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
+                                 int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream) {
+  using namespace ggq;
+  if (epilogue < GGQ_EPI_NONE || epilogue > GGQ_EPI_SILU_MUL || (epilogue != GGQ_EPI_NONE && !aux)) return GGQ_ERR_ARG;
+  if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
+  if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
+  if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (n_rows == 0 || batch == 0) return GGQ_OK;
+  if (!ggq_mmq_t16_supported(type, k, batch)) return ggq_mmq_t16_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
+  if (n_rows > 0x7fffffffLL - 64) return GGQ_ERR_SHAPE;
+  if (!w || !q || !y) return GGQ_ERR_ARG;
+  if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
+  const Epi16 ep{epilogue, aux};
+  hipStream_t s = (hipStream_t)stream;
+  switch (type) {
+    case GGQ_TYPE_Q4_K: return launch_t16_t<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q5_K: return launch_t16_t<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    default: return GGQ_ERR_TYPE;
+  }
+}

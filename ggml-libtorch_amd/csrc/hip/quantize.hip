@@ -27,10 +27,19 @@ __device__ __forceinline__ void load4(const void* x, int64_t base, int64_t ix, i
 // LAYOUT 2: the same 144 bytes per (128 elements, token), regrouped so that one MFMA B fragment
 //           (32 tokens x 32 elements) is 1 KB contiguous in lane order: per (ix/128, token/32) a
 //           4608-byte tile { int8 qs[4 groups][2 halves][32 tokens][16]; ds[2 pairs][32 tokens][2] }
+// LAYOUT 3: the same values for the 16-token-tile kernel (mmq_t16.hip): per (ix/256, token/16) a 4608-byte tile
+//           { int8 frag[4][4 K-chunks][16 tokens][16]; ds[2 halves][4 token quads][4 groups][4 tokens] } — one MFMA
+//           16x16x64 operand fragment is 1 KB contiguous in lane order (lane = token + 16 * K-chunk).  Which sixteen
+//           elements of the 256 a (fragment, K-chunk) slot holds depends on the WEIGHT format's bit layout (the slot's
+//           partner is the 16 bytes a weight lane loads): `inv` holds, per 16-element run v of the 256, its slot as
+//           nibble v (t16_inverse_perm below).
+// LAYOUT 4: LAYOUT 3 for at most 8 tokens, half the bytes: 2304-byte tiles { int8 frag[4][4 K-chunks][8 tokens][16];
+//           ds[2 halves][2 token quads][4 groups][4 tokens] } (what ggq_quantize_q8_1_t16 writes for batch <= 8).
 template <int DT, int LAYOUT, bool NEED_SUM>
 __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restrict__ x,
                                                             uint8_t* __restrict__ q, int64_t batch,
-                                                            int64_t k, int64_t padded, int64_t tok_off) {
+                                                            int64_t k, int64_t padded, int64_t tok_off,
+                                                            uint64_t inv) {
   const int64_t t = blockIdx.y + tok_off;
   // Lane l (bits b2 b1 b0) of an 8-lane group takes the 4-element chunk c = (b2, b1^b2, b0^b2) of its 32-group, so that the
   // three cross-lane levels of the reference's warp reduction (element ^16, ^8, ^4: ggml_kernel.cu quantize_q8_1, same fp32
@@ -81,6 +90,40 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
       const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
       *(uint32_t*)blk = (uint32_t)hd | ((uint32_t)hs << 16);
     }
+  } else if (LAYOUT == 4) {
+    // batch <= 8: per ix/256 a 2304-byte tile { int8 frag[4][4 K-chunks][8 tokens][16]; ds[2 halves][2 token quads][4 groups][4 tokens] }
+    uint8_t* tile = q + (g >> 3) * 2304;
+    const int e256 = (int)(ix & 255), tl = (int)(t & 7);
+    const int slot = (int)((inv >> (4 * (e256 >> 4))) & 15);
+    *(uint32_t*)(tile + (slot >> 2) * 512 + ((slot & 3) * 8 + tl) * 16 + (e256 & 15)) = packed;
+    if (e == 0) {
+      const int g8 = (int)(g & 7);
+      uint8_t* ds = tile + 2048 + ((((g8 >> 2) * 2 + (tl >> 2)) * 4 + (g8 & 3)) * 4 + (tl & 3)) * 4;
+      if (NEED_SUM) {
+        const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+        const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
+        *(uint32_t*)ds = (uint32_t)hd | ((uint32_t)hs << 16);
+      } else {
+        *(float*)ds = d;
+      }
+    }
+  } else if (LAYOUT == 3) {
+    const int64_t n_tt = (batch + 15) >> 4;
+    uint8_t* tile = q + ((g >> 3) * n_tt + (t >> 4)) * 4608;
+    const int e256 = (int)(ix & 255), tl = (int)(t & 15);
+    const int slot = (int)((inv >> (4 * (e256 >> 4))) & 15);   // fragment = slot >> 2, K-chunk = slot & 3
+    *(uint32_t*)(tile + (slot >> 2) * 1024 + ((slot & 3) * 16 + tl) * 16 + (e256 & 15)) = packed;
+    if (e == 0) {
+      const int g8 = (int)(g & 7);
+      uint8_t* ds = tile + 4096 + ((((g8 >> 2) * 4 + (tl >> 2)) * 4 + (g8 & 3)) * 4 + (tl & 3)) * 4;
+      if (NEED_SUM) {
+        const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+        const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
+        *(uint32_t*)ds = (uint32_t)hd | ((uint32_t)hs << 16);
+      } else {
+        *(float*)ds = d;
+      }
+    }
   } else if (LAYOUT == 2) {
     const int64_t n_tt = (batch + 31) >> 5;
     uint8_t* tile = q + ((g >> 2) * n_tt + (t >> 5)) * 4608;
@@ -114,7 +157,7 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
 
 template <int LAYOUT, bool NEED_SUM>
 static int launch_quant(const void* x, int dt, void* q, int64_t batch, int64_t k, int64_t padded,
-                        hipStream_t s) {
+                        hipStream_t s, uint64_t inv = 0) {
   if (batch == 0) return GGQ_OK;
   const dim3 block(256);
   const unsigned gx = (unsigned)((padded / 4 + 255) / 256);
@@ -126,15 +169,15 @@ static int launch_quant(const void* x, int dt, void* q, int64_t batch, int64_t k
     switch (dt) {
       case GGQ_F32:
         GGQ_HIP_PRE_LAUNCH();
-        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F32, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
+        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F32, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off, inv);
         break;
       case GGQ_F16:
         GGQ_HIP_PRE_LAUNCH();
-        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
+        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_F16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off, inv);
         break;
       case GGQ_BF16:
         GGQ_HIP_PRE_LAUNCH();
-        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_BF16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off);
+        hipLaunchKernelGGL((quantize_q8_1_kernel<GGQ_BF16, LAYOUT, NEED_SUM>), grid, block, 0, s, xo, qo, batch, k, padded, off, inv);
         break;
       default: return GGQ_ERR_DTYPE;
     }
@@ -143,7 +186,56 @@ static int launch_quant(const void* x, int dt, void* q, int64_t batch, int64_t k
   return GGQ_OK;
 }
 
+// Which 16-element run of a 256-element unit the (fragment f, K-chunk c) slot 4 f + c of the 16-token-tile layout holds,
+// per weight format — the mirror of what the weight lane (row, c) of mmq_t16.hip gets out of its 16 loaded bytes:
+//   Q4_K / Q5_K  f = 2 q + hi: lane c of load q holds bytes 16 (c & 1) .. + 15 of the 32-byte chunk of pair 2 q + (c >> 1);
+//                its low nibbles are elements 64 p + 16 (c & 1) + 0..15 (group 2 p), its high nibbles the same of group 2 p + 1
+//   legacy nibble formats (Q4_0 Q4_1 Q5_0 Q5_1): lane c of step s holds block 4 s + c: low nibbles = its elements 0..15,
+//                high nibbles = 16..31: f = 2 s + hi
+//   Q8_0         lane c of step s (64 elements) holds elements 64 s + 16 c .. + 15: identity
+static uint64_t t16_inverse_perm(int type) {
+  int perm[16];
+  for (int f = 0; f < 4; ++f)
+    for (int c = 0; c < 4; ++c) {
+      int v;
+      if (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K) v = 8 * (f >> 1) + 4 * (c >> 1) + 2 * (f & 1) + (c & 1);
+      else if (type == GGQ_TYPE_Q8_0) v = 4 * f + c;
+      else v = 2 * (4 * (f >> 1) + c) + (f & 1);
+      perm[4 * f + c] = v;
+    }
+  uint64_t inv = 0;
+  for (int s = 0; s < 16; ++s) inv |= (uint64_t)s << (4 * perm[s]);
+  return inv;
+}
+
 }  // namespace ggq
+
+extern "C" int ggq_mmq_t16_type_supported(int type) {
+  switch (type) {
+    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: return 1;
+    default: return 0;
+  }
+}
+
+extern "C" int ggq_quantize_q8_1_t16(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                                     int type, void* stream) {
+  using namespace ggq;
+  if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
+  if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (!ggq_mmq_t16_type_supported(type)) return GGQ_ERR_TYPE;
+  if (batch == 0) return GGQ_OK;
+  if (!x || !q) return GGQ_ERR_ARG;
+  if ((uintptr_t)q & 15) return GGQ_ERR_ALIGN;
+  const int64_t padded = ggq_mmq_padded_k(k);
+  const uint64_t inv = t16_inverse_perm(type);
+  if (batch <= 8) {   // the 8-token form of the layout (mmq_t16.hip's M8 mode)
+    if (ggq_mmq_need_sum(type)) return launch_quant<4, true>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream, inv);
+    return launch_quant<4, false>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream, inv);
+  }
+  if (ggq_mmq_need_sum(type))
+    return launch_quant<3, true>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream, inv);
+  return launch_quant<3, false>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream, inv);
+}
 
 extern "C" int ggq_quantize_q8_1(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
                                  void* stream) {

@@ -37,6 +37,10 @@ HIP_SYMBOLS = {
     "ggq_mul_mat_q_pretiled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "ggq_mul_mat_q_pretiled_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ggq_mul_mat_q_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "ggq_mmq_t16_type_supported": (c_int, [c_int]),
+    "ggq_mmq_t16_supported": (c_int, [c_int, c_int64, c_int64]),
+    "ggq_quantize_q8_1_t16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "ggq_mul_mat_q_t16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ggq_mul_mat_vec_q_prequant": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
     "ggq_peer_export": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
     "ggq_peer_import": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p)]),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 3   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_* */
+#define GGQ_ABI_VERSION 4   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16 */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -167,6 +167,21 @@ int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y, int type, 
 int ggq_mul_mat_q_epi(const void* w, const void* x, void* y, int type, int dtype,
                       int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                       int epilogue, const void* aux, void* scratch, void* stream);
+
+/* 16-token-tile path for the HBM-bound batches (what ggq_mul_mat_q runs between the GEMV-like batches and the 32-token
+ * MFMA tile for the formats ggq_mmq_t16_type_supported() reports; same role as mul_mat_q's small mmq_x instances,
+ * HK/ggml/kernel_instances/mmq_kernel.cuh:21-32 + mmq.cuh:1917-1986).  The scratch holds the same Q8_1 values as
+ * ggq_quantize_q8_1_mmq, regrouped per (k/256, token/16) into 4608-byte tiles { int8 frag[4][4 K-chunks][16 tokens][16];
+ * half2(d, sum) | float d  ds[2 halves][4 token quads][4 groups][4 tokens] } in the element order the weight format's
+ * MFMA operand needs (one operand fragment = 1 KB contiguous).  q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte
+ * aligned.  ggq_mul_mat_q_t16 takes the epilogue arguments of ggq_mul_mat_q_pretiled_epi. */
+int ggq_mmq_t16_type_supported(int type);
+int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch);
+int ggq_quantize_q8_1_t16(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                          int type, void* stream);
+int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype,
+                      int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
+                      int epilogue, const void* aux, void* stream);
 
 /* mul_mat_vec_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1). */
 int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, int dtype,

@@ -145,3 +145,84 @@ def assert_fp_accumulate(y_gpu, y_ref, yabs, dtype, what=""):
     bad = np.abs(y - ref) > tol
     assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} outside 1e-3 rel; worst "
                            f"{np.max(np.abs(y - ref) / tol):.2f}x tol at {np.unravel_index(np.argmax(np.abs(y - ref) / tol), ref.shape)}")
+
+
+# ---------------------------------------------------------------- 16-token-tile path (mmq_t16.hip)
+def t16_perm(t):
+    """slot 4 f + c of a 4608-byte tile -> which 16-element run of the 256-element unit it holds; written from the
+    weight formats' bit layouts (HK/ggml/ggml-common.h:17-108), independently of quantize.hip's t16_inverse_perm"""
+    t = GGMLType(int(t))
+    perm = []
+    for f in range(4):
+        for c in range(4):
+            if t in (GGMLType.Q4_K, GGMLType.Q5_K):
+                q, hi = divmod(f, 2)                 # 64-byte half of the nibble field, low / high nibbles
+                pair, half = 2 * q + (c >> 1), c & 1   # 32-byte chunk of the pair, its 16-byte half
+                perm.append((64 * pair + 32 * hi + 16 * half) // 16)
+            elif t == GGMLType.Q8_0:
+                perm.append(4 * f + c)
+            else:                                     # 32-element nibble blocks: lane c of step s holds block 4 s + c
+                s, hi = divmod(f, 2)
+                perm.append((32 * (4 * s + c) + 16 * hi) // 16)
+    assert sorted(perm) == list(range(16))
+    return perm
+
+
+def retile_q8_1_t16(q_mmq, batch, k, t):
+    """block_q8_1_mmq bytes (index (k/128)*batch + token) -> the 16-token-tile layout of ggq_quantize_q8_1_t16, built in
+    numpy: per (k/256, token/16) a 4608-byte tile { frag[4][4 K-chunks][16 tokens][16]; ds[2][4 quads][4 groups][4 tokens] }"""
+    padded = k - k % 512 + 512
+    n_kb, n_u, n_tt = padded // 128, padded // 256, (batch + 15) // 16
+    blocks = np.asarray(q_mmq, np.uint8)[:n_kb * batch * 144].reshape(n_kb, batch, 144)
+    perm = t16_perm(t)
+    if batch <= 8:   # the 8-token form: 2304-byte tiles { frag[4][4][8 tokens][16]; ds[2][2 quads][4 groups][4 tokens] }
+        out = np.zeros((n_u, 2304), np.uint8)
+        for tok in range(batch):
+            qs = blocks[:, tok, 16:].reshape(n_u, 256)
+            ds = blocks[:, tok, :16].reshape(n_u, 8, 4)
+            for slot, v in enumerate(perm):
+                f, c = divmod(slot, 4)
+                o = f * 512 + (c * 8 + tok) * 16
+                out[:, o:o + 16] = qs[:, 16 * v:16 * v + 16]
+            for g8 in range(8):
+                o = 2048 + ((((g8 >> 2) * 2 + (tok >> 2)) * 4 + (g8 & 3)) * 4 + (tok & 3)) * 4
+                out[:, o:o + 4] = ds[:, g8]
+        return out
+    out = np.zeros((n_u, n_tt, 4608), np.uint8)
+    for tok in range(batch):
+        tt, tl = divmod(tok, 16)
+        qs = blocks[:, tok, 16:].reshape(n_u, 256)          # the token's int8 values, unit by unit
+        ds = blocks[:, tok, :16].reshape(n_u, 8, 4)         # [unit][group of the unit][4 bytes]
+        for slot, v in enumerate(perm):
+            f, c = divmod(slot, 4)
+            o = f * 1024 + (c * 16 + tl) * 16
+            out[:, tt, o:o + 16] = qs[:, 16 * v:16 * v + 16]
+        for g8 in range(8):
+            o = 4096 + ((((g8 >> 2) * 4 + (tl >> 2)) * 4 + (g8 & 3)) * 4 + (tl & 3)) * 4
+            out[:, tt, o:o + 4] = ds[:, g8]
+    return out
+
+
+def gpu_quantize_q8_1_t16(x, t):
+    L = ggqlib.hip()
+    batch, k = x.shape
+    q = torch.zeros(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_quantize_q8_1_t16(vp(x), ggqlib.dtype_code(x.dtype), vp(q), batch, k, int(t), stream_ptr()), "quantize_t16")
+    torch.cuda.synchronize()
+    return q.cpu().numpy()
+
+
+def gpu_mmq_t16(w_np, x, t, n_rows, ldy=None, epilogue=0, aux=None, w_dev=None):
+    """quantise into the 16-token-tile scratch, then the 16-token-tile kernel alone"""
+    L = ggqlib.hip()
+    batch, k = x.shape
+    ldy = n_rows if ldy is None else ldy
+    w = dev_bytes(w_np) if w_dev is None else w_dev
+    y = torch.zeros((batch, ldy), dtype=x.dtype, device="cuda")
+    q = torch.empty(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    dt = ggqlib.dtype_code(x.dtype)
+    ggqlib.check(L.ggq_quantize_q8_1_t16(vp(x), dt, vp(q), batch, k, int(t), stream_ptr()), "quantize_t16")
+    ggqlib.check(L.ggq_mul_mat_q_t16(vp(w), vp(q), vp(y), int(t), dt, batch, k, n_rows, ldy, epilogue,
+                                     None if aux is None else vp(aux), stream_ptr()), "ggq_mul_mat_q_t16")
+    torch.cuda.synchronize()
+    return y
