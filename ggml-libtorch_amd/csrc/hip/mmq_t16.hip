@@ -75,12 +75,12 @@ template <int T> struct T16Fmt {
 // wave-private LDS (bytes): W [16 rows][MAXU units] raw bytes | TAB scale tables
 template <int T, bool M8, int NTT, int MAXU> struct T16Lds {
   static constexpr int SB = MAXU * T16Fmt<T>::UB;          // slice bytes of one row
-  static constexpr int NI = 16 * SB / 1024;                // DMA instructions (1 KB each) of the weight image
-  static_assert(16 * SB % 1024 == 0, "whole DMA instructions");
+  static constexpr int NI = (16 * SB + 1023) / 1024;       // DMA instructions (1 KB each) of the weight image (the last may be partial:
+                                                           // its surplus lanes repeat the final chunk into the padding)
   static constexpr int TT = M8 ? 256 : 512;                // scale table of one (unit, token tile)
   static constexpr int W = 0;
-  static constexpr int TAB = 16 * SB;
-  static constexpr int WAVE = TAB + NTT * MAXU * TT;
+  static constexpr int TAB = NI * 1024;
+  static constexpr int WAVE = TAB + (M8 ? 1024 : NTT * ((MAXU + 1) / 2) * 1024);   // whole table DMA instructions
   static constexpr int TILE = M8 ? 2304 : 4608;            // activation tile of one (unit, token tile)
   static constexpr int FRAG = M8 ? 512 : 1024;
 };
@@ -137,22 +137,22 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
   // ---- everything the wave reads of units [ub, ub + MAXU) is requested here by LDS-DMA: scale tables, then the weight
   //      image in row-major linear order (chunk n = 64 i + lane of instruction i: row n / CPR, 16-byte column n % CPR) ----
   auto request_round = [&](int ub) {
-    if constexpr (M8) {   // 256 bytes per unit: lane = (unit lane >> 4, 16 bytes lane & 15)
-      const uint32_t o = tile_off(min(ub + (lane >> 4), u1 - 1), 0) + 2048 + (lane & 15) * 16;
+    if constexpr (M8) {   // 256 bytes per unit: lane = (unit lane >> 4, 16 bytes lane & 15); units past MAXU land in the padding
+      const uint32_t o = tile_off(min(ub + min(lane >> 4, MAXU - 1), u1 - 1), 0) + 2048 + (lane & 15) * 16;
       __builtin_amdgcn_global_load_lds((t16_gptr)(q8 + o), (t16_lptr)(wl + L::TAB), 16, 0, 0);
     } else {
 #pragma unroll
       for (int jj = 0; jj < NTT; ++jj)
 #pragma unroll
-        for (int sp = 0; sp < MAXU / 2; ++sp) {   // 512 bytes per (unit, token tile): lanes 0-31 unit 2 sp, lanes 32-63 unit 2 sp + 1
+        for (int sp = 0; sp < (MAXU + 1) / 2; ++sp) {   // 512 bytes per (unit, token tile): lanes 0-31 unit 2 sp, lanes 32-63 unit 2 sp + 1
           const uint32_t o = tile_off(min(ub + 2 * sp + (lane >> 5), u1 - 1), jj) + 4096 + (lane & 31) * 16;
-          __builtin_amdgcn_global_load_lds((t16_gptr)(q8 + o), (t16_lptr)(wl + L::TAB + (jj * MAXU + 2 * sp) * 512), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((t16_gptr)(q8 + o), (t16_lptr)(wl + L::TAB + (jj * ((MAXU + 1) / 2) + sp) * 1024), 16, 0, 0);
         }
     }
     constexpr int CPR = SB / 16, CPU = UB / 16;   // 16-byte chunks per row slice / per unit
 #pragma unroll
     for (int i = 0; i < L::NI; ++i) {
-      const int n = 64 * i + lane;
+      const int n = min(64 * i + lane, 16 * CPR - 1);
       const int row = n / CPR, col = n - row * CPR;
       const int su = col / CPU, within = col - su * CPU;
       const uint8_t* src = wtile + ((uint32_t)min(row, rmax) * row_bytes + (uint32_t)min(ub + su, u1 - 1) * UB + 16 * within);
@@ -166,20 +166,51 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
   const uint32_t m_lo = c < 2 ? 0x0F0F0F0Fu : 0u, m_hi = c < 2 ? 0u : 0x0F0F0F0Fu;   // lanes of the unit half's first / second group pair
   const int sel = c >> 1;   // the lane's group pair within a unit half
 
-  // one unit: slot s of the round, fragments Fr
+  // one unit: slot s of the round, fragments Fr.  Every LDS read of the unit is issued before the first use (one wait
+  // instead of a read -> wait -> use chain per operand), the min term has its own accumulator (its MFMA chain does not
+  // serialise with the scaling FMAs).
+  v4f accm[NTT];   // min-term accumulators (f32 MFMA chain)
+#pragma unroll
+  for (int jj = 0; jj < NTT; ++jj) accm[jj] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
   auto compute_unit = [&](int s, const Frags& Fr) {
     const uint8_t* blk = wl + L::W + j * SB + s * UB;   // row j's block of this unit
-    // ---- row scales of the unit's 8 groups: d * sc_g and -(dmin * m_g)  (get_scale_min_k4, dequantize.cuh:154-161) ----
     const v4u_t hd = *(const v4u_t*)blk;   // {d | dmin << 16, scales[0..3], scales[4..7], scales[8..11]}
+    v4u_t qh = {0, 0, 0, 0};
+    if constexpr (F::has_qh) qh = *(const v4u_t*)(blk + off::Q5_K_QH + 16 * (c & 1));
+    v4u_t rawq[2];
+    rawq[0] = *(const v4u_t*)(blk + F::QS + 16 * c);
+    rawq[1] = *(const v4u_t*)(blk + F::QS + 64 + 16 * c);
+    // token scales: M8 [unit][half][token quad][group][token], else [token tile][unit][half][token quad][group][token]
+    constexpr bool HOIST = false;   // (hoisting every scale word above the first MFMA measured no gain: 86 -> 118 registers)
+    uint32_t sw[2][NTT];
+    v4u_t dsv[2][NTT][4];
+    auto read_scales = [&](int q, int jj) {
+      if constexpr (M8) {
+        const uint8_t* tq = wl + L::TAB + s * 256 + q * 128;
+        sw[q][jj] = *(const uint32_t*)(tq + ((j >> 2) & 1) * 64 + c * 16 + (j & 3) * 4);
+        dsv[q][jj][0] = *(const v4u_t*)(tq + (c & 1) * 64 + (2 * sel) * 16);
+        dsv[q][jj][1] = *(const v4u_t*)(tq + (c & 1) * 64 + (2 * sel + 1) * 16);
+      } else {
+        const uint8_t* tq = wl + L::TAB + (jj * ((MAXU + 1) / 2) * 2 + s) * 512 + q * 256;
+        sw[q][jj] = *(const uint32_t*)(tq + (j >> 2) * 64 + c * 16 + (j & 3) * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dsv[q][jj][g] = *(const v4u_t*)(tq + c * 64 + g * 16);   // tokens 4c .. 4c+3, group 4q + g
+      }
+    };
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int jj = 0; jj < NTT; ++jj) read_scales(q, jj);
+    }
+    // ---- row scales of the unit's 8 groups: d * sc_g and -(dmin * m_g)  (get_scale_min_k4, dequantize.cuh:154-161) ----
     const uint32_t s0 = hd[1], s1 = hd[2], s2 = hd[3];
     const uint32_t sc4[2] = {s0 & 0x3F3F3F3Fu, (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u)};
     const uint32_t mn4[2] = {s1 & 0x3F3F3F3Fu, ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u)};
     const float dall = bits_h_f32(hd[0] & 0xFFFF), dmin = bits_h_f32(hd[0] >> 16);
-    v4u_t qh = {0, 0, 0, 0};
-    if constexpr (F::has_qh) qh = *(const v4u_t*)(blk + off::Q5_K_QH + 16 * (c & 1));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const v4u_t raw = *(const v4u_t*)(blk + F::QS + 64 * q + 16 * c);
+      const v4u_t raw = rawq[q];
       v4i b_lo, b_hi;   // the lane's 16 elements of group 4q + 2 sel (low nibbles) and 4q + 2 sel + 1 (high nibbles)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -195,19 +226,19 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
       const float mwc = -(dmin * (float)((mn4[q] >> (8 * c)) & 0xFF));
       const v4i zero = {0, 0, 0, 0};
       if constexpr (M8) {
+        if constexpr (!HOIST) read_scales(q, 0);
         const float dw_lo = dall * (float)((sc4[q] >> (16 * sel)) & 0xFF), dw_hi = dall * (float)((sc4[q] >> (16 * sel + 8)) & 0xFF);
         const v4i C_lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][0][0], b_lo, zero, 0, 0, 0);
         const v4i C_hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][0][1], b_hi, zero, 0, 0, 0);
-        const uint8_t* tq = wl + L::TAB + s * 256 + q * 128;   // [token quad][group][token] half2(d8, s8)
-        const uint32_t sw = *(const uint32_t*)(tq + ((j >> 2) & 1) * 64 + c * 16 + (j & 3) * 4);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(j < 8 ? bits_h_f32(sw >> 16) : 0.0f, mwc, acc[0], 0, 0, 0);
-        const v4u_t ds_lo = *(const v4u_t*)(tq + (c & 1) * 64 + (2 * sel) * 16), ds_hi = *(const v4u_t*)(tq + (c & 1) * 64 + (2 * sel + 1) * 16);
+        // A rows 8-15 are the second group pair's copy of tokens 0-7: their min term is already in rows 0-7
+        const float s8a = j < 8 ? bits_h_f32(sw[q][0] >> 16) : 0.0f;
+        accm[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(s8a, mwc, accm[0], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           // float(C) * d8 rounded once (v_fma_mix_f32 reads the fp16 d8 in place), then the row scale (mmq.cuh:1274-1363 factors)
           float t0, t1;
-          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t0) : "v"((float)C_lo[r]), "v"(ds_lo[r]));
-          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t1) : "v"((float)C_hi[r]), "v"(ds_hi[r]));
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t0) : "v"((float)C_lo[r]), "v"(dsv[q][0][0][r]));
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t1) : "v"((float)C_hi[r]), "v"(dsv[q][0][1][r]));
           acc[0][r] = __builtin_fmaf(t0, dw_lo, acc[0][r]);
           acc[0][r] = __builtin_fmaf(t1, dw_hi, acc[0][r]);
         }
@@ -223,21 +254,19 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
         for (int g = 0; g < 4; ++g) dw[g] = dall * (float)((sc4[q] >> (8 * g)) & 0xFF);
 #pragma unroll
         for (int jj = 0; jj < NTT; ++jj) {
+          if constexpr (!HOIST) read_scales(q, jj);
           v4i C[4];
           C[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][0], b_a, zero, 0, 0, 0);
           C[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][1], b_b, zero, 0, 0, 0);
           C[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][0], b_c, zero, 0, 0, 0);
           C[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][1], b_d, zero, 0, 0, 0);
-          const uint8_t* tq = wl + L::TAB + (jj * MAXU + s) * 512 + q * 256;   // [token quad][group][token] half2(d8, s8)
-          const uint32_t sw = *(const uint32_t*)(tq + (j >> 2) * 64 + c * 16 + (j & 3) * 4);
-          acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(bits_h_f32(sw >> 16), mwc, acc[jj], 0, 0, 0);
+          accm[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(bits_h_f32(sw[q][jj] >> 16), mwc, accm[jj], 0, 0, 0);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const v4u_t ds = *(const v4u_t*)(tq + c * 64 + g * 16);   // tokens 4c .. 4c+3, group 4q + g
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float t;
-              asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t) : "v"((float)C[g][r]), "v"(ds[r]));
+              asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t) : "v"((float)C[g][r]), "v"(dsv[q][jj][g][r]));
               acc[jj][r] = __builtin_fmaf(t, dw[g], acc[jj][r]);
             }
           }
@@ -246,9 +275,11 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
     }
   };
 
+  // fragments: double-buffered one unit ahead; a single buffer when two token tiles make a unit's fragments 64 registers
+  constexpr bool DBUF = NTT == 1;
   Frags FA, FB;
   request_frags(FA, u0);
-  request_frags(FB, u0 + 1);
+  if constexpr (DBUF) { if (u0 + 1 < u1) request_frags(FB, u0 + 1); }
   for (int ub = u0; ub < u1; ub += MAXU) {
     request_round(ub);   // (slices longer than MAXU units: the previous round's LDS reads have all returned — their results were used)
     T16_STAMP(1);
@@ -258,17 +289,28 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
     __builtin_amdgcn_wave_barrier();
     T16_STAMP(2);
     const int ns = min(MAXU, u1 - ub);
+    if constexpr (DBUF) {
 #pragma unroll 1
-    for (int s = 0; s < ns; s += 2) {
-      compute_unit(s, FA);
-      if (s == 0) T16_STAMP(3);
-      request_frags(FA, ub + s + 2);
-      if (s + 1 < ns) compute_unit(s + 1, FB);
-      request_frags(FB, ub + s + 3);
+      for (int s = 0; s < ns; s += 2) {
+        compute_unit(s, FA);
+        if (s == 0) T16_STAMP(3);
+        if (ub + s + 2 < u1) request_frags(FA, ub + s + 2);   // (wave-uniform: nothing is requested past the slice)
+        if (s + 1 < ns) compute_unit(s + 1, FB);
+        if (ub + s + 3 < u1) request_frags(FB, ub + s + 3);
+      }
+    } else {
+#pragma unroll 1
+      for (int s = 0; s < ns; ++s) {
+        compute_unit(s, FA);
+        if (s == 0) T16_STAMP(3);
+        if (ub + s + 1 < u1) request_frags(FA, ub + s + 1);
+      }
     }
   }
 
   T16_STAMP(4);
+#pragma unroll
+  for (int jj = 0; jj < NTT; ++jj) acc[jj] += accm[jj];
   // ---- K-slice reduction: sums in slice order, the (token tile, register) pairs dealt round-robin to the waves ----
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the last (unused) fragment prefetch
   __syncthreads();
@@ -302,22 +344,20 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
   T16_STAMP(6);
 }
 
-template <int T, int DT, bool M8, int NTT>
-static int launch_t16(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
-                      Epi16 ep) {
-  constexpr int MAXU = 4, MAXKS = 12;
+template <int T, int DT, bool M8, int NTT, int MAXU>
+static int launch_t16_u(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
+                        Epi16 ep, int64_t ks) {
+  constexpr int MAXKS = M8 ? 16 : 12;   // waves per workgroup the kernel is compiled for (M8 fits 128 registers)
   using L = T16Lds<T, M8, NTT, MAXU>;
   const int64_t n_units = k / 256;
   const int64_t n_tt = M8 ? 1 : (batch + 15) / 16;
-  // K-slices: MAXU units per wave while that needs at most MAXKS waves (K <= 12288), longer slices (several LDS rounds) beyond
   constexpr size_t red = (size_t)NTT * 4 * 64 * 4;
   constexpr size_t wave = (size_t)L::WAVE > red ? (size_t)L::WAVE : red;
   constexpr int64_t LDS_KS = (160 * 1024) / wave;   // waves whose LDS areas fit one CU
-  int64_t ks = (n_units + MAXU - 1) / MAXU;
   if (ks > MAXKS) ks = MAXKS;
   if (ks > LDS_KS) ks = LDS_KS;
-  const int64_t ups = (n_units + ks - 1) / ks;
-  ks = (n_units + ups - 1) / ups;   // no empty slice
+  const int64_t ups = (n_units + ks - 1) / ks;   // > MAXU: slices of several LDS rounds
+  ks = (n_units + ups - 1) / ups;                // no empty slice
   const size_t lds = (size_t)ks * wave;
   const int64_t gy = (n_tt + NTT - 1) / NTT;
   const int64_t gx = (n + 15) / 16;
@@ -331,6 +371,27 @@ static int launch_t16(const void* w, const void* q8, void* y, int64_t batch, int
                      (int)n_units, (int)ups, (int)n, (int)batch, ldy, (int)n_tt, ep.kind, ep.aux);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
+}
+
+// K-slices: the fewest units per wave (2, 3 or 4 held in LDS at once) for which every workgroup of the grid is resident
+// at once — short slices mean a short per-wave chain of request -> land -> compute -> reduce and more waves to hide it
+// (stamps: one wave alone needs 0.84 us to issue a 4-unit slice's memory instructions and 0.45 us per unit), but a second
+// round of workgroups costs more than that saves (11008 x 4096, batch 8: 8.1 us with 2-unit slices in two rounds against
+// 6.9 us with 4-unit slices in one).
+template <int T, int DT, bool M8, int NTT>
+static int launch_t16(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
+                      Epi16 ep) {
+  constexpr int MAXKS = M8 ? 16 : 12;
+  constexpr int64_t WAVES_PER_CU = M8 ? 16 : 12;   // what the instances' register counts admit (4 / 3 waves per SIMD)
+  const int64_t n_units = k / 256;
+  const int64_t n_wg = ((n + 15) / 16) * (M8 ? 1 : ((batch + 15) / 16 + NTT - 1) / NTT);
+  auto resident = [&](int64_t maxu) {
+    const int64_t ks = (n_units + maxu - 1) / maxu;
+    return ks <= MAXKS && n_wg <= 256 * (WAVES_PER_CU / ks);
+  };
+  if (resident(2)) return launch_t16_u<T, DT, M8, NTT, 2>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 1) / 2);
+  if (resident(3)) return launch_t16_u<T, DT, M8, NTT, 3>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 2) / 3);
+  return launch_t16_u<T, DT, M8, NTT, 4>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 3) / 4);
 }
 
 template <int T, int DT>
