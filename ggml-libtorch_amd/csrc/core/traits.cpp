@@ -85,3 +85,44 @@ extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
   // whole 32-token tiles: the fragment-major layout (ggq_quantize_q8_1_tiled) addresses tiles
   return (size_t)((batch + 31) / 32 * 32) * (size_t)(ggq_mmq_padded_k(k) / 32 * 36);
 }
+
+// ---- which kernel ggq_mul_mat_q runs: the role of the reference's tile heuristic (mul_mat_q_case / get_mmq_x_max_host,
+// HK/ggml/kernel_instances/mmq_kernel.cuh:21-32, mmq.cuh:155-164), decided from the format, the batch AND the shape.
+// Host-only and exported so that the table can be tested without a GPU (tests/test_host_logic.py).
+extern "C" int ggq_mmq_t16_type_supported(int type) {
+  switch (type) {
+    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: return 1;
+    default: return 0;
+  }
+}
+
+extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
+  // 256-element units; 32-bit byte offsets into the activation scratch
+  if (!ggq_mmq_t16_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
+  if ((uint64_t)ggq_mmq_scratch_bytes(batch, k) >= (1ull << 31)) return 0;
+  if ((uint64_t)ggq_row_bytes(type, k) * 16 >= (1ull << 32)) return 0;   // 32-bit byte offsets inside a 16-row weight tile
+  return 1;
+}
+
+extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows) {
+  if (!ggq_mmq_type_supported(type) || batch <= 0 || k <= 0 || n_rows <= 0 || k % ggq_block_elems(type)) return GGQ_MMQ_ROUTE_NONE;
+  // The HBM-bound batches.  Measured (scripts/sweep_t16.py, op = quantise + kernel, us warm / cold, old route -> 16-token tiles):
+  //   Q4_K 11008 x 4096   b2  8.8/11.6 ->  9.0/12.0   b3 10.4/12.8 -> 8.9/12.0   b8 15.2/16.4 -> 9.3/12.2   b16 15.8/19.9 -> 11.6/13.9
+  //                       b32 15.8/19.7 -> 15.0/17.9  b33 20.4/24.0 -> 23.0/25.1
+  //   Q4_K 3584 x 8192    b2 11.8/13.9 ->  8.1/ 9.8   b8 22.5/23.8 -> 8.3/10.2   b32 16.5/20.4 -> 12.8/14.5   b64 20.1/24.0 -> 21.2/22.9
+  //   Q4_K 4096 x 11008   b2 16.1/18.8 ->  9.5/12.0   b8 31.3/31.9 -> 9.8/12.2   b32 20.6/26.3 -> 15.1/17.9
+  //   Q5_K 11008 x 4096   b8 15.2/18.7 -> 10.6/13.5   b16 18.0/20.2 -> 12.6/15.1   b32 15.8/20.2 -> 18.5/21.2
+  // i.e. every shape from batch 2 (a tie at the one shape whose row count suits the dot4 kernel's 4096 waves) up to the
+  // last batch one workgroup column covers without re-reading the weights: 32 tokens (two token tiles) for Q4_K, 16 for
+  // Q5_K whose two-tile instance sits at the register limit.
+  if (ggq_mmq_t16_supported(type, k, batch) && batch >= 2 && batch <= (type == GGQ_TYPE_Q4_K ? 32 : 16)) return GGQ_MMQ_ROUTE_T16;
+  // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):
+  // the dot4 kernel while it beats the streamed one with the weights coming from HBM, the barrier-coupled LDS-tile
+  // kernel for the mid batches of the two formats whose streamed instance is bound by its weight copy, streamed beyond.
+  const bool dot4_to_8 = type == GGQ_TYPE_Q4_0 || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_0 || type == GGQ_TYPE_Q5_1 ||
+                         type == GGQ_TYPE_Q4_K;
+  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? 65 : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 : 5;
+  const bool streamable = ggq_row_bytes(type, k) <= (32 << 20);   // ggq_mmq_tiled_supported: 32-bit offsets in a 32-row tile
+  if (streamable && batch >= stream_from) return GGQ_MMQ_ROUTE_STREAM;
+  return batch <= 8 ? GGQ_MMQ_ROUTE_DOT4 : GGQ_MMQ_ROUTE_LDS_TILE;
+}

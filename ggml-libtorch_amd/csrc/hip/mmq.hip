@@ -1472,23 +1472,20 @@ extern "C" int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type,
                                 int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                                 void* scratch, void* stream) {
   if (!scratch) return GGQ_ERR_ARG;
-  // Q4_K / Q5_K beyond the GEMV-like batches: fragment-major activations + the streamed kernel
-  // (batch <= 4 stays on the dot4 kernel: 8.1 / 10.9 us vs 14.2 us at the headline shape)
-  // Measured r1 on 11008 x 4096 (kernel only, us; dot4 / LDS-tile kernel vs streamed):
-  //   Q4_K b8 19.7/16.3  b32 20.4/16.5  b128 40.9/31.3 | Q4_0 b8 18.0/15.4  b128 39.3/30.6
-  //   Q8_0 b8 18.4/25.1  b64 26.5/29.1  b128 42.9/42.3 | Q6_K b16 26.7/28.9  b64 48.0/38.5  b128 73.8/61.5
-  // batch <= 4 stays on the dot4 kernel for every format (Q4_K: 8.1 / 10.9 us at batch 1 / 4 vs 14.2 us).
-  // Round 2, op incl. the quantise launch, streamed / dot4 at batch 8 (us, warm | cold; scripts/sweep_batch.py): Q4_0 14.8/13.9 |
-  //   19.1/16.1, Q4_1 15.8/14.6 | 19.0/15.8, Q5_0 16.4/15.5 | 22.5/17.1, Q5_1 16.2/15.9 | 21.4/17.0, Q4_K 13.4/14.8 | 18.5/15.9 (the
-  //   weights of a layer are streamed from HBM in real use: the cold column decides), Q5_K 15.3/17.9 | 18.9/20.3,
-  //   Q2_K 15.0/18.3 | 16.1/18.6, Q3_K 19.4/25.3 | 21.5/30.7: the dot4 kernel keeps batches up to 8 for the first five.
-  const bool dot4_to_8 = type == GGQ_TYPE_Q4_0 || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_0 || type == GGQ_TYPE_Q5_1 ||
-                         type == GGQ_TYPE_Q4_K;
-  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? 65 : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 : 5;
-  if (ggq_mmq_tiled_supported(type, k) && batch >= stream_from) {
-    const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
-    if (rc != GGQ_OK) return rc;
-    return ggq_mul_mat_q_pretiled(w, scratch, y, type, dtype, batch, k, n_rows, ldy, stream);
+  // kernel selection: ggq_mmq_route (csrc/core/traits.cpp) — format, batch and shape; the measurements behind every
+  // threshold are recorded there
+  switch (ggq_mmq_route(type, batch, k, n_rows)) {
+    case GGQ_MMQ_ROUTE_T16: {
+      const int rc = ggq_quantize_q8_1_t16(x, dtype, scratch, batch, k, type, stream);
+      if (rc != GGQ_OK) return rc;
+      return ggq_mul_mat_q_t16(w, scratch, y, type, dtype, batch, k, n_rows, ldy, GGQ_EPI_NONE, nullptr, stream);
+    }
+    case GGQ_MMQ_ROUTE_STREAM: {
+      const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
+      if (rc != GGQ_OK) return rc;
+      return ggq_mul_mat_q_pretiled(w, scratch, y, type, dtype, batch, k, n_rows, ldy, stream);
+    }
+    default: break;   // dot4 / LDS-tile kernels on the reference layout; argument errors are reported by the callee
   }
   int rc = ggq_quantize_q8_1_mmq(x, dtype, scratch, batch, k, type, stream);
   if (rc != GGQ_OK) return rc;
@@ -1499,6 +1496,11 @@ extern "C" int ggq_mul_mat_q_epi(const void* w, const void* x, void* y, int type
                                  int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* scratch,
                                  void* stream) {
   if (!scratch) return GGQ_ERR_ARG;
+  if (ggq_mmq_route(type, batch, k, n_rows) == GGQ_MMQ_ROUTE_T16) {
+    const int rc = ggq_quantize_q8_1_t16(x, dtype, scratch, batch, k, type, stream);
+    if (rc != GGQ_OK) return rc;
+    return ggq_mul_mat_q_t16(w, scratch, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream);
+  }
   if (!ggq_mmq_tiled_supported(type, k)) return ggq_mmq_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
   const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
   if (rc != GGQ_OK) return rc;

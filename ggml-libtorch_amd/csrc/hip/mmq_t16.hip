@@ -415,13 +415,6 @@ static int launch_t16_t(const void* w, const void* q8, void* y, int dt, int64_t 
 
 }  // namespace ggq
 
-extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
-  // 32-bit byte offsets into the activation scratch and into a weight row
-  if (!ggq_mmq_t16_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
-  if ((uint64_t)ggq_mmq_scratch_bytes(batch, k) >= (1ull << 31)) return 0;
-  return 1;
-}
-
 extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
                                  int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream) {
   using namespace ggq;

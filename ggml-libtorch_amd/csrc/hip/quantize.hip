@@ -210,13 +210,6 @@ static uint64_t t16_inverse_perm(int type) {
 
 }  // namespace ggq
 
-extern "C" int ggq_mmq_t16_type_supported(int type) {
-  switch (type) {
-    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: return 1;
-    default: return 0;
-  }
-}
-
 extern "C" int ggq_quantize_q8_1_t16(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
                                      int type, void* stream) {
   using namespace ggq;

@@ -106,8 +106,8 @@ torch::Tensor ggml_mul_mat_a8(torch::Tensor W, torch::Tensor X, int64_t type, in
     Y = torch::empty({X.size(0), X.size(1), row}, options);
   }
   if (batch == 0 || row == 0) return Y;
-  // reference: {batch, padded/32*9} ints (mmq.cu:208); here whatever the kernel behind ggq_mul_mat_q needs
-  // (whole 32-token tiles; fp32 token scales + stream-K fix-up slots from batch 17): ggq_mmq_scratch_bytes
+  // reference: {batch, padded/32*9} ints (mmq.cu:208); here the same bytes per token with the batch rounded up to whole
+  // 32-token tiles (the fragment-major layouts address tiles): ggq_mmq_scratch_bytes
   const int64_t scratch_ints = (int64_t)((ggq_mmq_scratch_bytes(batch, col) + 3) / 4);
   at::Tensor quant_X = torch::empty({scratch_ints}, torch::TensorOptions().dtype(torch::kInt32).device(W.device()));
   const int rc = ggq_mul_mat_q(W.data_ptr(), X.data_ptr(), Y.data_ptr(), (int)type, dt, batch, col, row,

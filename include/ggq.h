@@ -183,6 +183,14 @@ int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype
                       int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                       int epilogue, const void* aux, void* stream);
 
+/* Which kernel ggq_mul_mat_q / _ld / _epi run for a (type, batch, k, n_rows): the role of the reference's tile
+ * heuristic (mul_mat_q_case + get_mmq_x_max_host, HK/ggml/kernel_instances/mmq_kernel.cuh:21-32, mmq.cuh:155-164).
+ * Host-only, no GPU needed.  DOT4 = batch <= 8 GEMV-like kernel, LDS_TILE = barrier-coupled kernel on the reference
+ * layout, STREAM = 32 / 64-token MFMA units on the fragment-major scratch, T16 = 16-token tiles (ggq_mul_mat_q_t16). */
+enum ggq_mmq_route_id { GGQ_MMQ_ROUTE_NONE = 0, GGQ_MMQ_ROUTE_DOT4 = 1, GGQ_MMQ_ROUTE_LDS_TILE = 2, GGQ_MMQ_ROUTE_STREAM = 3,
+                        GGQ_MMQ_ROUTE_T16 = 4 };
+int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows);
+
 /* mul_mat_vec_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1). */
 int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, int dtype,
                                int64_t k, int64_t n_rows, void* stream);

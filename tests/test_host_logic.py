@@ -51,3 +51,44 @@ def test_no_compat_layers_in_kernels():
         txt = open(os.path.join(hipdir, f)).read()
         for banned in ("__HIP_PLATFORM_AMD__", "USE_ROCM", "cuda_runtime", "__CUDA_ARCH__", "hipify", "triton"):
             assert banned not in txt, f"{f} contains {banned}"
+
+
+def test_mmq_routing_table():
+    """ggq_mmq_route (the tile heuristic's role, mmq_kernel.cuh:21-32): shape-aware, monotone in the batch per regime,
+    and consistent with what each kernel supports.  Host-only: the CPU library exports the same function."""
+    from ggq import lib as ggqlib
+    L = ggqlib.cpu()
+    NONE, DOT4, LDS_TILE, STREAM, T16 = range(5)
+    Q4_K, Q5_K, Q4_0, Q8_0, Q6_K = 12, 13, 2, 8, 14
+    shapes = [(4096, 11008), (11008, 4096), (8192, 3584), (8192, 28672), (256, 16), (4096 + 32, 64)]
+    for k, n in shapes:
+        for t in WEIGHT_TYPES:
+            prev = None
+            for b in (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 512):
+                r = L.ggq_mmq_route(int(t), b, k, n)
+                if k % BLOCK[t][0]:
+                    assert r == NONE
+                    continue
+                assert r in (DOT4, LDS_TILE, STREAM, T16)
+                if r == T16:
+                    assert L.ggq_mmq_route(int(t), b, k, n) == T16 and k % 256 == 0 and 2 <= b <= 32
+                if r == DOT4:
+                    assert b <= 8
+                prev = r
+    # the HBM-bound batches of the formats with a 16-token-tile kernel, at every BASELINE shape
+    for k, n in shapes[:4]:
+        for b in (2, 5, 8, 16, 32):
+            assert L.ggq_mmq_route(Q4_K, b, k, n) == T16
+        for b in (2, 8, 16):
+            assert L.ggq_mmq_route(Q5_K, b, k, n) == T16
+        assert L.ggq_mmq_route(Q5_K, 32, k, n) == STREAM
+        assert L.ggq_mmq_route(Q4_K, 1, k, n) == DOT4 and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
+        assert L.ggq_mmq_route(Q4_K, 128, k, n) == STREAM
+        assert L.ggq_mmq_route(Q8_0, 8, k, n) == DOT4 and L.ggq_mmq_route(Q8_0, 64, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
+        assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM
+        assert L.ggq_mmq_route(Q4_0, 8, k, n) == DOT4 and L.ggq_mmq_route(Q4_0, 9, k, n) == STREAM
+    # invalid inputs
+    assert L.ggq_mmq_route(1, 8, 4096, 64) == NONE and L.ggq_mmq_route(Q4_K, 0, 4096, 64) == NONE
+    assert L.ggq_mmq_route(20, 8, 4096, 64) == NONE   # IQ4_NL: no GEMM
+    # 32-bit offsets: a scratch of 2 GiB or more stays off the 16-token-tile kernel
+    assert L.ggq_mmq_route(Q4_K, 32, 1 << 26, 64) != T16 and L.ggq_mmq_route(Q4_K, 32, 1 << 21, 64) == T16
