@@ -1,0 +1,34 @@
+"""kernel-only timing of ggq_mul_mat_q_t16 for one or more libraries. usage: python scripts/sweep_t16k.py type rows k batches... (GGQ_LIBS=a.so,b.so)"""
+import sys, os, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ggml-libtorch_amd"))
+import torch
+from ggq import lib as ggqlib, synth
+t, N, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]); batches = [int(a) for a in sys.argv[4:]]
+libs = [("default", ggqlib.hip())] + [(os.path.basename(p), ggqlib._bind(ctypes.CDLL(p), ggqlib.HIP_SYMBOLS)) for p in os.environ.get("GGQ_LIBS", "").split(",") if p]
+vp = lambda x: ctypes.c_void_p(x.data_ptr()); st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+w0 = torch.from_numpy(synth.random_weight(t, N, K, seed=0)).cuda()
+nring = max(2, (352 << 20) // w0.numel() + 2)
+ws = [w0] + [w0.clone() for _ in range(nring - 1)]
+def timeit(f, cold):
+    for i in range(4): f(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(64): f(i if cold else 0)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000 / 128
+for b in batches:
+    x = torch.randn((b, K), generator=torch.Generator().manual_seed(0)).half().cuda()
+    y = torch.empty((b, N), dtype=torch.float16, device="cuda"); yref = None
+    scr = torch.empty(int(libs[0][1].ggq_mmq_scratch_bytes(b, K)) + 4096, dtype=torch.uint8, device="cuda")
+    assert libs[0][1].ggq_quantize_q8_1_t16(vp(x), 1, vp(scr), b, K, t, st()) == 0
+    for name, L in libs:
+        def f(i): assert L.ggq_mul_mat_q_t16(vp(ws[i % nring]), vp(scr), vp(y), t, 1, b, K, N, N, 0, None, st()) == 0
+        a, c = timeit(f, 0), timeit(f, 1)
+        f(0); torch.cuda.synchronize()
+        same = "" if yref is None else (" same" if torch.equal(y, yref) else " DIFFERENT max|d|=%g" % (y.float() - yref.float()).abs().max().item())
+        if yref is None: yref = y.clone()
+        print(f"type {t} {N}x{K} batch {b:3d} {name:22s}: kernel {a:6.2f} / {c:6.2f} us warm/cold{same}", flush=True)
