@@ -48,7 +48,7 @@ Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 = 12, 13, 14, 2, 8
 NAMES = {Q4_K: "Q4_K", Q4_0: "Q4_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q6_K: "Q6_K"}
 K_DIM, N_DIM, BATCH = 4096, 11008, 128
 COLD_BYTES = 352 << 20   # distinct bytes a "cold" ring must span: 256 MiB Infinity Cache + 32 MiB L2 + margin
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def algo_bytes_matmul(t, n_rows, k, batch, esz=2):
@@ -290,32 +290,52 @@ def strong_scaling_config5(L, dev, world, rank, dist):
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 us = float(tt.item())
             entry[name] = {"us": round(us, 2)}
-        if world > 1 and os.environ.get("GGQ_BENCH_PEER") == "1":
-            # opt-in (never run on a multi-GPU node by this build: a fault here must not cost the default scaling run):
-            # the peer-mapped direct-write gather (ggq.dist.PeerSlabGather: HIP IPC, device-to-device stores over xGMI,
-            # host barrier) instead of the RCCL all-gather; wall clock around kernel + push + barrier
+        if world > 1 and os.environ.get("GGQ_BENCH_PEER", "1") != "0":
+            # the peer-mapped direct-write gather (ggq.dist.PeerSlabGather: HIP IPC mapping, one scatter kernel that stores the
+            # slab into every peer's buffer over xGMI and publishes a device flag, one wait kernel; no RCCL, no host barrier)
+            # beside the RCCL column.  Never run across GPUs by the build that wrote it (one-GPU box): every step is guarded,
+            # and the ranks exchange an ok flag so that a failure on one rank cannot desynchronise the collectives that follow.
+            err, us_peer, pg = None, None, None
             try:
                 from ggq.dist import PeerSlabGather
                 pg = PeerSlabGather(b, N5, torch.float16, dev)
+
                 def peer_step():
+                    out = pg.local
                     if b == 1:
-                        rc = L.ggq_mul_mat_vec_q(vp(w5), vp(x), vp(pg.local), Q4_K, 1, K5, rows, vp(sc), cur_stream())
+                        rc = L.ggq_mul_mat_vec_q(vp(w5), vp(x), vp(out), Q4_K, 1, K5, rows, vp(sc), cur_stream())
                     else:
-                        rc = L.ggq_mul_mat_q_ld(vp(w5), vp(x), vp(pg.local), Q4_K, 1, b, K5, rows, rows, vp(sc), cur_stream())
+                        rc = L.ggq_mul_mat_q_ld(vp(w5), vp(x), vp(out), Q4_K, 1, b, K5, rows, rows, vp(sc), cur_stream())
                     assert rc == 0, rc
                     pg.gather()
                 for _ in range(3):
                     peer_step()
-                t0 = time.perf_counter()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 for _ in range(20):
                     peer_step()
-                us = (time.perf_counter() - t0) * 1e6 / 20
-                tt = torch.tensor([us], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                entry["end_to_end_peer_write"] = {"us": round(float(tt.item()), 2), "timing": "wall clock, kernel + peer writes + stream drain + host barrier"}
-                pg.close()
+                e1.record()
+                e1.synchronize()
+                us_peer = e0.elapsed_time(e1) * 1e3 / 20
+                if pg.status() != 0:
+                    err = "ggq_peer_wait timed out on a peer"
             except Exception as ex:  # pragma: no cover
-                entry["end_to_end_peer_write"] = {"error": repr(ex)[:300]}
+                err = repr(ex)[:300]
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            try:
+                if pg is not None:
+                    pg.close()
+            except Exception as ex:  # pragma: no cover
+                errs.append(repr(ex)[:200])
+            if any(e is not None for e in errs):
+                entry["end_to_end_peer_write"] = {"error": [e for e in errs if e is not None][:2]}
+            else:
+                tt = torch.tensor([us_peer], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                entry["end_to_end_peer_write"] = {"us": round(float(tt.item()), 2),
+                                                  "timing": "HIP events, kernel + scatter kernel (peer stores + device flag) + wait kernel, 20 iterations, max over ranks"}
         nbytes = algo_bytes_matmul(Q4_K, N5, K5, b)
         entry["end_to_end"]["GB/s_whole_job"] = round(nbytes / (entry["end_to_end"]["us"] * 1e-6) / 1e9, 1)
         entry["message_bytes_per_rank"] = b * rows * 2
@@ -432,6 +452,7 @@ def main():
         # gather buffers in the [P, batch, rows] form (slot r = rank r's [batch, rows] slab; ggq.dist.unpermute_gathered
         # turns it into [batch, P * rows] where a consumer needs that layout)
         gathered = [torch.empty((world * BATCH, N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]
+        full = [torch.empty((BATCH, world * N_DIM), dtype=torch.float16, device=dev) for _ in range(2)]   # [batch, P * rows]: what a consumer reads
         # (events are created once and re-recorded: per-step host overhead matters at ~30 us of GPU work per step)
         ready_ev = [torch.cuda.Event(), torch.cuda.Event()]
         done_ev = [torch.cuda.Event(), torch.cuda.Event()]
@@ -448,6 +469,8 @@ def main():
             comm.wait_event(ready_ev[b])
             with torch.cuda.stream(comm):
                 dist.all_gather_into_tensor(gathered[b], ys[b])
+                # [P, batch, rows] -> [batch, P * rows] inside the timed region (one permute copy on the side stream)
+                full[b].view(BATCH, world, N_DIM).copy_(gathered[b].view(world, BATCH, N_DIM).permute(1, 0, 2))
                 done_ev[b].record(comm)
             used[b] = True
 
@@ -462,7 +485,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
-        launch_mode = "eager launches, all-gather overlapped on a side stream"
+        launch_mode = "eager launches, all-gather + un-permute to [batch, P * rows] overlapped on a side stream"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -506,17 +529,20 @@ def main():
         st_warm = time_launches(lambda i: mmq_only(i, [w]), 208, use_graph=not args.eager)
         achieved = bytes_per_step / (st_cold["us"] * 1e-6) / 1e9
         ops = 2.0 * BATCH * N_DIM * K_DIM
-        traffic, traffic_note = None, "profiles/r02_traffic.json absent"
+        traffic, traffic_note = None, "profiles/r03_traffic.json absent"
         try:   # PMC-derived HBM bytes per launch, measured offline with rocprofv3 (profiles/); refused when the kernel changed since
             tj = json.load(open(TRAFFIC_JSON))
             src = hashlib.sha256(open(os.path.join(ROOT, "ggml-libtorch_amd", "csrc", "hip", "mmq.hip"), "rb").read()).hexdigest()
             if tj.get("mmq_hip_sha256") == src:
                 traffic, traffic_note = tj["mmq_q4_k_batch128"]["hbm_bytes_per_launch"], tj["mmq_q4_k_batch128"].get("how", "")
             else:
-                traffic_note = "profiles/r02_traffic.json was measured on a different mmq.hip (sha mismatch): stale, not reported"
+                traffic_note = "profiles/r03_traffic.json was measured on a different mmq.hip (sha mismatch): stale, not reported"
         except Exception:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "ggq::mmq_stream_kernel<Q4_K, f16, TB=2> (32 rows x 64 tokens x 4 K-slices per workgroup)",
+        # `frac` prices the kernel against the HBM roof (the metric is GB/s + % of the HBM roofline) although at batch 128 it
+        # is bound by the SIMD's own instruction issue (vector + matrix work, which do not overlap on this SIMD): `bound` says
+        # so, and `frac_int8_mfma_peak` is the same duration against the dense int8 MFMA peak
+        out["roofline"] = {"bound": "valu+mfma issue (hbm is the metric's roof: frac; int8 mfma: frac_int8_mfma_peak)", "kernel": "ggq::mmq_stream_kernel<Q4_K, f16, TB=2> (32 rows x 64 tokens x 4 K-slices per workgroup)",
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                            "avg_launch_us": st_cold["us"], "p10_launch_us": st_cold["p10"], "p90_launch_us": st_cold["p90"],
@@ -591,6 +617,31 @@ def secondary_configs(L, dev, w_q4k, w_q4k_ring, x128, scratch, args):
         rec(f"mmq_{NAMES[t]}_batch8",
             lambda b, t=t: L.ggq_mul_mat_q(vp(b[0]), vp(x8), vp(y128), t, 1, 8, K_DIM, N_DIM, vp(scratch), cur_stream()),
             [rings[t]], algo_bytes_matmul(t, N_DIM, K_DIM, 8), 2.0 * 8 * N_DIM * K_DIM)
+    # the HBM-bound batches between the GEMV and the 32-token tile (Q4_K: the 16-token-tile kernel, mmq_t16.hip)
+    for bb in (2, 16, 32, 64):
+        xb = x128[:bb].contiguous()
+        rec(f"mmq_Q4_K_batch{bb}",
+            lambda b, bb=bb, xb=xb: L.ggq_mul_mat_q(vp(b[0]), vp(xb), vp(y128), Q4_K, 1, bb, K_DIM, N_DIM, vp(scratch), cur_stream()),
+            [rings[Q4_K]], algo_bytes_matmul(Q4_K, N_DIM, K_DIM, bb), 2.0 * bb * N_DIM * K_DIM, iters=52)
+    # north_star: Q8_0 at batch 1 too (MMVQ)
+    rec("mmvq_Q8_0_batch1",
+        lambda b: L.ggq_mul_mat_vec_q(vp(b[0]), vp(x1), vp(y1), Q8_0, 1, K_DIM, N_DIM, vp(sc1), cur_stream()),
+        [rings[Q8_0]], algo_bytes_matmul(Q8_0, N_DIM, K_DIM, 1), 2.0 * N_DIM * K_DIM, iters=208)
+    # the transposed (down-projection) shape: K = 11008, N = 4096
+    KT, NT = N_DIM, K_DIM
+    wT = torch.from_numpy(synth.random_weight(Q4_K, NT, KT, seed=3)).to(dev)
+    ringT = ring_of(wT, wT.numel())
+    xT = torch.randn((BATCH, KT), generator=torch.Generator().manual_seed(7)).half().to(dev)
+    yT = torch.empty((BATCH, NT), dtype=torch.float16, device=dev)
+    scT = torch.empty(max(int(L.ggq_mmq_scratch_bytes(BATCH, KT)), int(L.ggq_mmvq_scratch_bytes(KT))), dtype=torch.uint8, device=dev)
+    for bb in (1, 8, 128):
+        xb = xT[:bb].contiguous()
+        if bb == 1:
+            fn = lambda b, xb=xb: L.ggq_mul_mat_vec_q(vp(b[0]), vp(xb), vp(yT), Q4_K, 1, KT, NT, vp(scT), cur_stream())
+        else:
+            fn = lambda b, bb=bb, xb=xb: L.ggq_mul_mat_q(vp(b[0]), vp(xb), vp(yT), Q4_K, 1, bb, KT, NT, vp(scT), cur_stream())
+        rec(f"transposed_4096x11008_Q4_K_batch{bb}", fn, [ringT], algo_bytes_matmul(Q4_K, NT, KT, bb), 2.0 * bb * NT * KT, iters=52)
+    del ringT, wT
     st = time_launches(lambda i: L.ggq_quantize_q8_1_mmq(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 208, use_graph=g)
     res["quantize_mmq_q8_1_batch128"] = dict(st, cache_state="warm: 1 MB of activations, 0.7 MB of scratch")
     st = time_launches(lambda i: L.ggq_quantize_q8_1_tiled(vp(x128), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream()), 208, use_graph=g)

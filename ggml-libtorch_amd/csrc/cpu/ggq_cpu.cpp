@@ -192,6 +192,10 @@ extern "C" int ggq_cpu_dequantize_f32_ex(const void* w, float* out, int type, in
   if (!w || !out) return GGQ_ERR_ARG;
   const int64_t nb = k / 32;
   int nt = nthreads < 1 ? 1 : nthreads;
+  // threads are created per call (no pool: the library keeps no state), so a thread is only worth starting for at least
+  // 4 MiB of output (32768 blocks) — with 64 threads on 64 MiB the call measured thread creation, not dequantisation
+  const int64_t max_useful = (nb + 32767) / 32768;
+  if ((int64_t)nt > max_useful) nt = (int)max_useful;
   if ((int64_t)nt > nb) nt = (int)nb;
   if (nt == 1) { fn((const uint8_t*)w, out, 0, nb); return GGQ_OK; }
   std::vector<std::thread> th;

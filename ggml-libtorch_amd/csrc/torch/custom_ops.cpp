@@ -5,15 +5,11 @@
 // input and raises on an unsupported type instead of returning uninitialised memory.
 #include <torch/extension.h>
 
-#include <cstdlib>
-#include <thread>
-
 #include "../../../include/ggq.h"
 
-static int default_threads() {
-  if (const char* e = std::getenv("GGQ_CPU_THREADS")) { int v = std::atoi(e); if (v > 0) return v; }
-  return 1;  // the reference loop is single-threaded (ggml-cpu/ggml-quants.hpp)
-}
+// the reference loop is single-threaded (ggml-cpu/ggml-quants.hpp); so is the op (no environment is read: a caller that
+// wants threads calls ggq_cpu_dequantize_f32_ex through the C ABI)
+static int default_threads() { return 1; }
 
 static torch::Tensor ggml_dequantize(const torch::Tensor W, int type, int64_t m, int64_t n) {
   TORCH_CHECK(W.device().is_cpu(), "custom_ops.ggml_dequantize: W must be a CPU tensor");

@@ -96,16 +96,23 @@ class SlabGather:
 
 
 class PeerSlabGather:
-    """Gather without a collective: every rank maps the other ranks' [P, batch, rows] buffers (ggq_peer_export / _import:
-    HIP IPC) and WRITES its slab straight into slot `rank` of each of them — device-to-device stores that cross xGMI
-    when the ranks own different GPUs.  Same interface as SlabGather (`local`, `gather()`, `buf`, `batch_major()`).
+    """Gather without a collective and without the host: every rank maps the other ranks' gather buffers (ggq_peer_export /
+    _import: HIP IPC) and `gather()` enqueues, on the current stream, ONE kernel that stores the rank's slab straight into
+    slot `rank` of each peer's buffer (device-to-device stores that cross xGMI when the ranks own different GPUs) and
+    publishes a generation number into the peers' flag words once every storing workgroup has released its stores at
+    system scope, followed by one tiny kernel that waits for the peers' flags (ggq_peer_scatter / ggq_peer_wait).  No
+    stream drain, no host barrier, no RCCL; the pair can be captured in a HIP graph.
 
-    `local` is the rank's slot of its own buffer: the matmul writes there (out= / ldy).  `gather()` pushes that slab to
-    the peers on the current stream, drains the stream and meets the other ranks at a barrier of the (CPU-capable)
-    process group, after which `buf` holds every rank's slab.  This is the first step of the direct-write path of
-    SURVEY 8e: the copy still follows the kernel instead of being the kernel's own stores, and the hand-off is a host
-    barrier rather than a device flag; it needs no RCCL and has been exercised with two processes sharing one GPU
-    (tests/test_peer_gather.py) — no multi-GPU node was available to this build."""
+    Same interface as SlabGather: the matmul writes the rank's slab into `local` (out= / ldy), `gather()` makes `buf`
+    ([P, batch, rows]) complete for everything enqueued behind it on the stream, `batch_major()` is the [batch, N] copy.
+    TWO buffers alternate by call parity: a fast rank's gather i + 1 writes the other buffer, so it cannot overwrite slabs
+    a slow peer's consumers of gather i still read; by the time it reaches gather i + 2 (the same buffer again) it has
+    waited for that peer's gather-(i + 1) slab, which the peer's stream produced after those consumers.  `local` / `buf`
+    always name the buffer of the NEXT / LAST `gather()` respectively.
+    `close()` is collective (barrier, unmap, barrier) and is also run by a context manager; a rank that fails inside
+    `gather()` still reaches the status exchange.  Exercised with two and three processes sharing one GPU
+    (tests/test_peer_gather.py: several gathers in a loop with a consumer kernel in between); no multi-GPU node was
+    available to this build."""
 
     def __init__(self, batch: int, n_rows: int, dtype, device, group=None):
         import ctypes
@@ -116,14 +123,28 @@ class PeerSlabGather:
         self.rank = dist.get_rank(group)
         if n_rows % self.world:
             raise ValueError("PeerSlabGather needs equal shards (n_rows % world_size == 0)")
+        if self.world > 9:
+            raise ValueError("PeerSlabGather: at most 8 peers")
         self.batch, self.rows = batch, n_rows // self.world
-        self.buf = torch.empty((self.world, batch, self.rows), dtype=dtype, device=device)
+        esz = torch.empty((), dtype=dtype).element_size()
+        if (self.rows * esz) % 16:
+            raise ValueError("PeerSlabGather needs slab rows of a multiple of 16 bytes")
+        self._slab_bytes = batch * self.rows * esz
+        self._buf_bytes = -(-self.world * self._slab_bytes // 256) * 256
+        # one allocation: [2 parities]{ [P] slabs, 256-byte aligned } | [2][P] flag words | arrivals word | status word
+        self._flags_off = 2 * self._buf_bytes
+        total = self._flags_off + 2 * 64 * 4 + 256
+        self._mem = torch.zeros(total, dtype=torch.uint8, device=device)
+        self._bufs = [self._mem[p * self._buf_bytes:p * self._buf_bytes + self.world * self._slab_bytes].view(dtype).view(self.world, batch, self.rows)
+                      for p in range(2)]
+        self._arrivals = self._mem.data_ptr() + self._flags_off + 2 * 64 * 4
+        self._status = self._arrivals + 64
         handle = (ctypes.c_ubyte * 64)()
         off = ctypes.c_int64(0)
-        ggqlib.check(self.L.ggq_peer_export(ctypes.c_void_p(self.buf.data_ptr()), handle, ctypes.byref(off)), "ggq_peer_export")
-        mine = (bytes(handle), int(off.value))
+        ggqlib.check(self.L.ggq_peer_export(ctypes.c_void_p(self._mem.data_ptr()), handle, ctypes.byref(off)), "ggq_peer_export")
+        torch.cuda.synchronize(device)   # the zeroed flags are in memory before any peer can write them
         everyone = [None] * self.world
-        dist.all_gather_object(everyone, mine, group=group)
+        dist.all_gather_object(everyone, (bytes(handle), int(off.value)), group=group)
         self._peer_ptr, self._peer_off = {}, {}
         for p, (h, o) in enumerate(everyone):
             if p == self.rank:
@@ -132,32 +153,84 @@ class PeerSlabGather:
             hb = (ctypes.c_ubyte * 64).from_buffer_copy(h)
             ggqlib.check(self.L.ggq_peer_import(hb, o, ctypes.byref(ptr)), "ggq_peer_import")
             self._peer_ptr[p], self._peer_off[p] = ptr.value, o
-        self._slab_bytes = batch * self.rows * self.buf.element_size()
+        self._calls = 0
+        self._closed = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     @property
     def local(self) -> torch.Tensor:
-        return self.buf[self.rank]
+        """the rank's slot of the buffer the NEXT gather() completes"""
+        return self._bufs[self._calls & 1][self.rank]
+
+    @property
+    def buf(self) -> torch.Tensor:
+        """[P, batch, rows] of the LAST gather() (before the first: of the next)"""
+        return self._bufs[(self._calls - 1) & 1 if self._calls else 0]
 
     def gather(self):
         import ctypes
         from . import lib as ggqlib
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.buf.device).cuda_stream)
-        row_bytes = self.rows * self.buf.element_size()
-        src = ctypes.c_void_p(self.local.data_ptr())
-        for p, base in self._peer_ptr.items():   # slot `rank` of peer p's buffer
-            dst = ctypes.c_void_p(base + self.rank * self._slab_bytes)
-            ggqlib.check(self.L.ggq_peer_write_2d(dst, row_bytes, src, row_bytes, row_bytes, self.batch, stream), "ggq_peer_write_2d")
-        torch.cuda.current_stream(self.buf.device).synchronize()
-        dist.barrier(group=self.group)
+        par = self._calls & 1
+        gen = (self._calls >> 1) + 1                  # generation of this parity's buffer
+        dev = self._mem.device
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        peers = sorted(self._peer_ptr)
+        n = len(peers)
+        row_bytes = self.rows * self._mem.new_empty(0, dtype=self._bufs[0].dtype).element_size()
+        ok, err = True, None
+        try:
+            dsts = (ctypes.c_void_p * max(n, 1))(*[self._peer_ptr[p] + par * self._buf_bytes + self.rank * self._slab_bytes for p in peers])
+            # peer p's flag word for THIS rank, in peer p's memory
+            flg = (ctypes.c_void_p * max(n, 1))(*[self._peer_ptr[p] + self._flags_off + (par * 64 + self.rank) * 4 for p in peers])
+            src = ctypes.c_void_p(self._bufs[par][self.rank].data_ptr())
+            ggqlib.check(self.L.ggq_peer_scatter(src, row_bytes, dsts, flg, n, row_bytes, row_bytes, self.batch, gen,
+                                                 ctypes.c_void_p(self._arrivals), stream), "ggq_peer_scatter")
+            # my own flag words, one per source rank: contiguous [P] words of parity `par`; wait for the peers' entries
+            # (the rank's own word is published here so that one contiguous poll covers all P)
+            my_flags = self._mem.data_ptr() + self._flags_off + par * 64 * 4
+            self._mem[self._flags_off + (par * 64 + self.rank) * 4:self._flags_off + (par * 64 + self.rank) * 4 + 4].view(torch.int32).fill_(gen)
+            ggqlib.check(self.L.ggq_peer_wait(ctypes.c_void_p(my_flags), self.world, gen, ctypes.c_void_p(self._status), stream), "ggq_peer_wait")
+        except Exception as e:   # keep the ranks in step: the failure is reported by close() / status()
+            ok, err = False, e
+        self._calls += 1
+        if not ok:
+            raise err
         return None
+
+    def status(self) -> int:
+        """0, or 1 if a ggq_peer_wait gave up on a peer (synchronises the device)"""
+        return int(self._mem[self._flags_off + 2 * 64 * 4 + 64:self._flags_off + 2 * 64 * 4 + 68].view(torch.int32).item())
 
     def batch_major(self) -> torch.Tensor:
         return unpermute_gathered(self.buf)
 
     def close(self):
-        for p, base in list(self._peer_ptr.items()):
-            self.L.ggq_peer_close(base, self._peer_off[p])
+        """collective: every rank's outstanding writes have landed and been consumed before any mapping goes away"""
+        if self._closed:
+            return
+        self._closed = True
+        torch.cuda.synchronize(self._mem.device)
+        dist.barrier(group=self.group)
+        rcs = [self.L.ggq_peer_close(base, self._peer_off[p]) for p, base in list(self._peer_ptr.items())]
         self._peer_ptr.clear()
+        dist.barrier(group=self.group)
+        if any(rc != 0 for rc in rcs):
+            raise RuntimeError(f"ggq_peer_close failed: {rcs}")
+
+    def __del__(self):
+        # never collective from a finaliser: only drop the mappings if close() was skipped
+        try:
+            if not self._closed:
+                for p, base in list(self._peer_ptr.items()):
+                    self.L.ggq_peer_close(base, self._peer_off[p])
+        except Exception:
+            pass
 
 
 def unpermute_gathered(buf: torch.Tensor) -> torch.Tensor:

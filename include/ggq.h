@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 4   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16 */
+#define GGQ_ABI_VERSION 5   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -224,6 +224,21 @@ int ggq_peer_import(const void* handle_64_bytes, int64_t offset, void** dev_ptr_
 int ggq_peer_close(void* dev_ptr, int64_t offset);
 int ggq_peer_write_2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t row_bytes,
                       int64_t rows, void* stream);
+/* Device-side hand-off of the gather (ABI 5; no host barrier, no stream drain, graph-capturable):
+ * ggq_peer_scatter: one kernel stores the rank's [rows x row_bytes] slab into `dsts[0..n_dst)` (slot `rank` of each peer's
+ *   buffer, mapped with ggq_peer_import; pitches in bytes, 16-byte multiples) and, once every workgroup has drained and
+ *   released its stores at system scope, writes `generation` into `flags[d]` (a 4-byte word in peer d's memory, one per
+ *   source rank).  `arrivals` is a zero-initialised 4-byte device word of the caller's own memory (workgroup count-in; the
+ *   kernel leaves it zero).  `dsts` / `flags` are HOST arrays of device pointers, at most 8 peers.
+ * ggq_peer_wait: one tiny kernel on `stream` that returns once the rank's own `flags[0..n_src)` all hold `generation`
+ *   (signed wrap-around compare), then acquires at system scope: work enqueued behind it sees every peer's slab.  A peer
+ *   that has not arrived after about two seconds sets *status (a 4-byte device word) to 1 instead of hanging the device.
+ * Generations increase by one per gather; a buffer must not be rewritten while a peer may still read the previous
+ * contents (ggq.dist.PeerSlabGather alternates two buffers). */
+int ggq_peer_scatter(const void* src, int64_t src_pitch, void* const* dsts, void* const* flags, int n_dst,
+                     int64_t dst_pitch, int64_t row_bytes, int64_t rows, uint32_t generation, void* arrivals,
+                     void* stream);
+int ggq_peer_wait(const void* flags, int n_src, uint32_t generation, void* status, void* stream);
 
 #ifdef __cplusplus
 }

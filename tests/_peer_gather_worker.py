@@ -21,16 +21,24 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t, batch, k, n_rows = GGMLType.Q4_K, 40, 1024, 64 * world
     w = synth.random_weight(t, n_rows, k, seed=11)
-    x = torch.randn((batch, k), generator=torch.Generator().manual_seed(12)).half().cuda()
     s, e = shard_rows(n_rows, world, rank)
-    pg = PeerSlabGather(batch, n_rows, torch.float16, x.device)
-    # the rank's slab, written by the matmul into its own slot (row pitch = rows of the slot)
-    y_local = util.gpu_mmq(w[s:e], x, t, e - s)
-    pg.local.copy_(y_local)
-    pg.gather()
-    full = util.gpu_mmq(w, x, t, n_rows)    # the one-GPU result: every slab is computed by the same kernels
-    ok = torch.equal(pg.batch_major(), full)
-    pg.close()
+    ok = True
+    with PeerSlabGather(batch, n_rows, torch.float16, torch.device("cuda", 0)) as pg:
+        consumed = []
+        for it in range(6):   # several gathers back to back, a consumer kernel of the gathered buffer in between, NO host
+            # synchronisation inside the loop: a rank that runs ahead must not overwrite slabs a slower peer still reads
+            x = torch.randn((batch, k), generator=torch.Generator().manual_seed(12 + it)).half().cuda()
+            y_local = util.gpu_mmq(w[s:e], x, t, e - s)
+            if rank == it % world:
+                torch.cuda._sleep(20_000_000)   # ~10 ms of device time: this rank lags behind the others
+            pg.local.copy_(y_local)
+            pg.gather()
+            consumed.append((x, (pg.batch_major().float() * 2.0)))   # the consumer: reads the gathered buffer on the stream
+        torch.cuda.synchronize()
+        assert pg.status() == 0, "a ggq_peer_wait timed out"
+        for x, got in consumed:
+            full = util.gpu_mmq(w, x, t, n_rows)    # the one-GPU result: every slab is computed by the same kernels
+            ok = ok and torch.equal(got, full.float() * 2.0)
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
     dist.destroy_process_group()
