@@ -25,6 +25,8 @@ extern "C" int ggq_block_elems(int type) {
       return 32;
     case GGQ_TYPE_Q2_K: case GGQ_TYPE_Q3_K: case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K:
     case GGQ_TYPE_Q6_K: case GGQ_TYPE_IQ4_XS:
+    case GGQ_TYPE_IQ2_XXS: case GGQ_TYPE_IQ2_XS: case GGQ_TYPE_IQ2_S: case GGQ_TYPE_IQ3_XXS: case GGQ_TYPE_IQ3_S:
+    case GGQ_TYPE_IQ1_S: case GGQ_TYPE_IQ1_M:
       return 256;
     default: return 0;
   }
@@ -45,6 +47,13 @@ extern "C" int ggq_block_bytes(int type) {
     case GGQ_TYPE_Q6_K: return 210;
     case GGQ_TYPE_IQ4_NL: return 18;    // block_iq4_nl, HK/ggml/ggml-common.h:176-182
     case GGQ_TYPE_IQ4_XS: return 136;   // block_iq4_xs, HK/ggml/ggml-common.h:184-191
+    case GGQ_TYPE_IQ2_XXS: return 66;   // block_iq2_xxs ... block_iq1_m, HK/ggml/ggml-common.h:108-168
+    case GGQ_TYPE_IQ2_XS: return 74;
+    case GGQ_TYPE_IQ2_S: return 82;
+    case GGQ_TYPE_IQ3_XXS: return 98;
+    case GGQ_TYPE_IQ3_S: return 110;
+    case GGQ_TYPE_IQ1_S: return 50;
+    case GGQ_TYPE_IQ1_M: return 56;
     default: return 0;
   }
 }
@@ -62,7 +71,7 @@ extern "C" int ggq_type_supported(int type) {
 
 // the ten cases of ggml_mul_mat_a8's switch (HK/ggml/mmq.cu:222-251): no IQ format
 extern "C" int ggq_mmq_type_supported(int type) {
-  return ggq_type_supported(type) && type != GGQ_TYPE_IQ4_NL && type != GGQ_TYPE_IQ4_XS;
+  return ggq_type_supported(type) && !(type >= GGQ_TYPE_IQ2_XXS && type <= GGQ_TYPE_IQ4_XS) && type != GGQ_TYPE_IQ1_M;
 }
 
 // mmq_need_sum, HK/ggml/mmq.cu:84-106

@@ -23,6 +23,7 @@
 // Tried for the cold case without gain: nontemporal stores (+-0), two ADJACENT chunks per thread (49 -> 40 %: a lane's
 // stores are then 32 bytes apart), a grid-stride loop that touches the next chunk's bytes one iteration ahead (45 %).
 #include "ggq_common.h"
+#include "iq_common.h"
 
 #ifndef GGQ_DEQUANT_CH
 // 8-element chunks per thread, 256 chunks apart (so that every store instruction of a wave still writes 1 KiB
@@ -259,6 +260,65 @@ template <> struct Decode<GGQ_TYPE_IQ4_XS> {
   }
 };
 
+// The grid-codebook IQ formats (HK/ggml/dequantize.cuh:256-398, 471-512): chunk `sub` = 8-element run il = sub & 3 of
+// 32-element sub-block ib = sub >> 2 (the reference's thread (il, ib)); fp32 arithmetic  d * grid[j] * (+-1)  with
+// d = half2float(x.d) * (0.5f + scale) * 0.25f | 0.5f evaluated left to right, ONE rounding to fp16.  (Multiplying by
+// +-1 commutes with the rounding: the product with the signed grid value is the same number, zero signs included.)
+template <int T> struct IqDecode {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    uint32_t lo, hi;
+    float mul;
+    IqRun<T>::get(b, sub >> 2, sub & 3, lo, hi, mul);
+    const float d = bits_h_f32(ld_u16(b)) * mul * IqRun<T>::post;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float p0 = d * (float)(int8_t)(lo >> (8 * e)), p1 = d * (float)(int8_t)(hi >> (8 * e));
+      asm volatile("" : "+v"(p0), "+v"(p1));   // plain v_mul_f32 (see iq4_chunk: a fused mix-fma would lose the sign of -0)
+      y[e] = (_Float16)p0;
+      y[4 + e] = (_Float16)p1;
+    }
+  }
+};
+template <> struct Decode<GGQ_TYPE_IQ2_XXS> : IqDecode<GGQ_TYPE_IQ2_XXS> {};
+template <> struct Decode<GGQ_TYPE_IQ2_XS> : IqDecode<GGQ_TYPE_IQ2_XS> {};
+template <> struct Decode<GGQ_TYPE_IQ2_S> : IqDecode<GGQ_TYPE_IQ2_S> {};
+template <> struct Decode<GGQ_TYPE_IQ3_XXS> : IqDecode<GGQ_TYPE_IQ3_XXS> {};
+template <> struct Decode<GGQ_TYPE_IQ3_S> : IqDecode<GGQ_TYPE_IQ3_S> {};
+
+// IQ1_S / IQ1_M (dequantize.cuh:354-398): y = d * (q + delta), q in {0, 1, 2} from the 2048-entry grid, delta = -1 +- 0.125,
+// d = half2float(d) * (2 * scale3 + 1)
+__device__ __forceinline__ void iq1_emit(uint32_t lo, uint32_t hi, float d, float delta, _Float16* y) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float p0 = d * ((float)(int8_t)(lo >> (8 * e)) + delta), p1 = d * ((float)(int8_t)(hi >> (8 * e)) + delta);
+    asm volatile("" : "+v"(p0), "+v"(p1));
+    y[e] = (_Float16)p0;
+    y[4 + e] = (_Float16)p1;
+  }
+}
+template <> struct Decode<GGQ_TYPE_IQ1_S> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int ib = sub >> 2, il = sub & 3;
+    const uint32_t qh = ld_u16(b + off::IQ1_S_QH + 2 * ib);
+    uint32_t lo, hi;
+    iq1_grid(b[off::IQ1_S_QS + 4 * ib + il] | (((qh >> (3 * il)) & 7) << 8), lo, hi);
+    const float delta = (qh & 0x8000) ? -1.0f - IQ1_DELTA : -1.0f + IQ1_DELTA;
+    iq1_emit(lo, hi, bits_h_f32(ld_u16(b + off::IQ1_S_D)) * (float)(2 * ((qh >> 12) & 7) + 1), delta, y);
+  }
+};
+template <> struct Decode<GGQ_TYPE_IQ1_M> {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+    const int ib = sub >> 2, il = sub & 3;
+    const int ib16 = 2 * ib + (il >> 1);
+    const uint32_t sc = ld_u16(b + off::IQ1_M_SC + 2 * (ib16 >> 2));
+    const uint32_t qh = b[off::IQ1_M_QH + ib16] >> (4 * (il & 1));
+    uint32_t lo, hi;
+    iq1_grid(b[off::IQ1_M_QS + 4 * ib + il] | ((qh & 7) << 8), lo, hi);
+    const float delta = (qh & 0x08) ? -1.0f - IQ1_DELTA : -1.0f + IQ1_DELTA;
+    iq1_emit(lo, hi, iq1m_super_scale(b) * (float)(2 * ((sc >> (3 * (ib16 & 3))) & 7) + 1), delta, y);
+  }
+};
+
 // CH = 8-element chunks per thread, 256 apart (GGQ_DEQUANT_CH above).
 template <int T, int CH>
 __global__ void __launch_bounds__(256) dequant_kernel(const uint8_t* __restrict__ w,
@@ -323,6 +383,13 @@ extern "C" int ggq_dequantize_f16(const void* w, void* out, int type, int64_t m,
     case GGQ_TYPE_Q6_K: return launch_dequant<GGQ_TYPE_Q6_K>(w, out, k, s);
     case GGQ_TYPE_IQ4_NL: return launch_dequant<GGQ_TYPE_IQ4_NL>(w, out, k, s);
     case GGQ_TYPE_IQ4_XS: return launch_dequant<GGQ_TYPE_IQ4_XS>(w, out, k, s);
+    case GGQ_TYPE_IQ2_XXS: return launch_dequant<GGQ_TYPE_IQ2_XXS>(w, out, k, s);
+    case GGQ_TYPE_IQ2_XS: return launch_dequant<GGQ_TYPE_IQ2_XS>(w, out, k, s);
+    case GGQ_TYPE_IQ2_S: return launch_dequant<GGQ_TYPE_IQ2_S>(w, out, k, s);
+    case GGQ_TYPE_IQ3_XXS: return launch_dequant<GGQ_TYPE_IQ3_XXS>(w, out, k, s);
+    case GGQ_TYPE_IQ3_S: return launch_dequant<GGQ_TYPE_IQ3_S>(w, out, k, s);
+    case GGQ_TYPE_IQ1_S: return launch_dequant<GGQ_TYPE_IQ1_S>(w, out, k, s);
+    case GGQ_TYPE_IQ1_M: return launch_dequant<GGQ_TYPE_IQ1_M>(w, out, k, s);
     default: return GGQ_ERR_TYPE;
   }
 }

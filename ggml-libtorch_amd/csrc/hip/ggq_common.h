@@ -62,6 +62,13 @@ GGQ_FMT(GGQ_TYPE_Q5_K, 256, 176)
 GGQ_FMT(GGQ_TYPE_Q6_K, 256, 210)
 GGQ_FMT(GGQ_TYPE_IQ4_NL, 32, 18)
 GGQ_FMT(GGQ_TYPE_IQ4_XS, 256, 136)
+GGQ_FMT(GGQ_TYPE_IQ2_XXS, 256, 66)
+GGQ_FMT(GGQ_TYPE_IQ2_XS, 256, 74)
+GGQ_FMT(GGQ_TYPE_IQ2_S, 256, 82)
+GGQ_FMT(GGQ_TYPE_IQ3_XXS, 256, 98)
+GGQ_FMT(GGQ_TYPE_IQ3_S, 256, 110)
+GGQ_FMT(GGQ_TYPE_IQ1_S, 256, 50)
+GGQ_FMT(GGQ_TYPE_IQ1_M, 256, 56)
 #undef GGQ_FMT
 
 // byte offsets inside a block (HK/ggml/ggml-common.h:20-108)

@@ -19,6 +19,7 @@
 //   * one wave per row group, ROWS rows in flight per wave for memory-level parallelism,
 //     64-lane shuffle reduction at the end of each row.
 #include "ggq_common.h"
+#include "iq_common.h"
 #include <type_traits>
 
 #ifndef GGQ_MMVQ_UNROLL
@@ -373,6 +374,91 @@ template <> struct UnitDot<GGQ_TYPE_IQ4_XS> {
   }
 };
 
+// The grid-codebook IQ formats (vecdotq.cuh:607-826, launchers mmvq.cuh:130-209: vdr 1, one 32-element sub-block per
+// lane): unit u = sub-block u & 7 of super-block u >> 3.  Signed grid bytes x q8 with v_dot4 (exact), then the reference's
+// float expression for the format.
+__device__ __forceinline__ int iq_dot8(uint32_t lo, uint32_t hi, const int8_t* a8) {
+  const v2i a = *(const v2i*)a8;
+  return sdot4((int)hi, a[1], sdot4((int)lo, a[0], 0));
+}
+template <int T> struct IqUnitDot {   // IQ2_XXS, IQ3_XXS, IQ3_S: one scale per sub-block; IQ2_XS, IQ2_S: one per 16 elements
+  static constexpr int UPB = 8;
+  static constexpr bool split = T == GGQ_TYPE_IQ2_XS || T == GGQ_TYPE_IQ2_S;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)(u >> 3) * Fmt<T>::BS;
+    const int ib = u & 7;
+    int sumi[2] = {0, 0};
+    float mul[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+      uint32_t lo, hi;
+      float m;
+      IqRun<T>::get(b, ib, il, lo, hi, m);
+      sumi[il >> 1] += iq_dot8(lo, hi, A.xq + 32 * u + 8 * il);
+      mul[il >> 1] = m;
+    }
+    const float dh = bits_h_f32(ld_u16(b));
+    if constexpr (split) {   // d * ((0.5f + ls1) * sumi1 + (0.5f + ls2) * sumi2), d = half2float(d) * d8 * 0.25f
+      const float d = dh * A.xd[u] * IqRun<T>::post;
+      return d * (mul[0] * (float)sumi[0] + mul[1] * (float)sumi[1]);
+    } else {                 // d * sumi, d = half2float(d) * (0.5f + scale) * d8 * post
+      const float d = dh * mul[0] * A.xd[u] * IqRun<T>::post;
+      return d * (float)(sumi[0] + sumi[1]);
+    }
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_IQ2_XXS> : IqUnitDot<GGQ_TYPE_IQ2_XXS> {};
+template <> struct UnitDot<GGQ_TYPE_IQ2_XS> : IqUnitDot<GGQ_TYPE_IQ2_XS> {};
+template <> struct UnitDot<GGQ_TYPE_IQ2_S> : IqUnitDot<GGQ_TYPE_IQ2_S> {};
+template <> struct UnitDot<GGQ_TYPE_IQ3_XXS> : IqUnitDot<GGQ_TYPE_IQ3_XXS> {};
+template <> struct UnitDot<GGQ_TYPE_IQ3_S> : IqUnitDot<GGQ_TYPE_IQ3_S> {};
+
+template <> struct UnitDot<GGQ_TYPE_IQ1_S> {   // vecdotq.cuh:750-781
+  static constexpr int UPB = 8;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)(u >> 3) * 50;
+    const int ib = u & 7;
+    const uint32_t qh = ld_u16(b + off::IQ1_S_QH + 2 * ib);
+    const uint32_t qs = ld_u32(b + off::IQ1_S_QS + 4 * ib);
+    int sumi = 0;
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+      uint32_t lo, hi;
+      iq1_grid(((qs >> (8 * il)) & 0xFF) | (((qh >> (3 * il)) & 7) << 8), lo, hi);
+      sumi += iq_dot8(lo, hi, A.xq + 32 * u + 8 * il);
+    }
+    const float d1q = bits_h_f32(ld_u16(b)) * (float)(((qh >> 11) & 0x0E) + 1);
+    const float delta = -1.0f + IQ1_DELTA - (float)(qh & 0x8000) * (2.0f * IQ1_DELTA / 0x8000);
+    return d1q * (A.xd[u] * (float)sumi + A.xs[u] * delta);
+  }
+};
+template <> struct UnitDot<GGQ_TYPE_IQ1_M> {   // vecdotq.cuh:783-826
+  static constexpr int UPB = 8;
+  static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) {
+    const uint8_t* b = row + (int64_t)(u >> 3) * 56;
+    const int ib = u & 7;
+    const uint32_t qs = ld_u32(b + off::IQ1_M_QS + 4 * ib);
+    const uint32_t qh2 = ld_u16(b + off::IQ1_M_QH + 2 * ib);
+    int sumi[2] = {0, 0};
+    float sumf[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+      const uint32_t qhl = (qh2 >> (8 * (il >> 1))) >> (4 * (il & 1));
+      uint32_t lo, hi;
+      iq1_grid(((qs >> (8 * il)) & 0xFF) | ((qhl & 7) << 8), lo, hi);
+      const v2i a = *(const v2i*)(A.xq + 32 * u + 8 * il);
+      sumi[il >> 1] = sdot4((int)hi, a[1], sdot4((int)lo, a[0], sumi[il >> 1]));
+      const float delta = -1.0f + IQ1_DELTA - (float)(qhl & 0x08) * (2.0f * IQ1_DELTA / 0x08);
+      const int sumy = sdot4(0x01010101, a[1], sdot4(0x01010101, a[0], 0));
+      sumf[il >> 1] += delta * (float)sumy;
+    }
+    const float d = iq1m_super_scale(b) * A.xd[u];
+    const uint32_t tmp = ld_u16(b + off::IQ1_M_SC + 2 * (ib >> 1)) >> (6 * (ib & 1));
+    const int sc0 = 2 * (int)(tmp & 7) + 1, sc1 = 2 * (int)((tmp >> 3) & 7) + 1;
+    return d * (((float)sumi[0] + sumf[0]) * (float)sc0 + ((float)sumi[1] + sumf[1]) * (float)sc1);
+  }
+};
+
 // LDS bytes for a row of k activations: int8[k] + float[k/32]*2 + int[k/16]
 static inline size_t mmvq_lds_bytes(int64_t k) { return (size_t)k + (size_t)(k / 32) * 8 + (size_t)(k / 16) * 4; }
 
@@ -604,6 +690,13 @@ static int mmvq_dispatch(const void* w, const void* q, void* y, int type, int dt
     case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, fused, s);
     case GGQ_TYPE_IQ4_NL: return launch_mmvq<GGQ_TYPE_IQ4_NL>(w, q, y, dtype, k, n_rows, fused, s);
     case GGQ_TYPE_IQ4_XS: return launch_mmvq<GGQ_TYPE_IQ4_XS>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ2_XXS: return launch_mmvq<GGQ_TYPE_IQ2_XXS>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ2_XS: return launch_mmvq<GGQ_TYPE_IQ2_XS>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ2_S: return launch_mmvq<GGQ_TYPE_IQ2_S>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ3_XXS: return launch_mmvq<GGQ_TYPE_IQ3_XXS>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ3_S: return launch_mmvq<GGQ_TYPE_IQ3_S>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ1_S: return launch_mmvq<GGQ_TYPE_IQ1_S>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_IQ1_M: return launch_mmvq<GGQ_TYPE_IQ1_M>(w, q, y, dtype, k, n_rows, fused, s);
     default: return GGQ_ERR_TYPE;
   }
 }

@@ -18,8 +18,16 @@ class GGMLType(IntEnum):
     Q4_K = 12
     Q5_K = 13
     Q6_K = 14
-    IQ4_NL = 20   # dequantise + MMVQ only (HK/ggml/ggml_kernel.cu:164-168, 179-183)
+    # the IQ formats: dequantise + MMVQ only (HK/ggml/ggml_kernel.cu:145-189)
+    IQ2_XXS = 16
+    IQ2_XS = 17
+    IQ3_XXS = 18
+    IQ1_S = 19
+    IQ4_NL = 20
+    IQ3_S = 21
+    IQ2_S = 22
     IQ4_XS = 23
+    IQ1_M = 29
 
 
 # type -> (elements per block, bytes per block)
@@ -29,12 +37,15 @@ BLOCK = {
     GGMLType.Q2_K: (256, 84), GGMLType.Q3_K: (256, 110), GGMLType.Q4_K: (256, 144),
     GGMLType.Q5_K: (256, 176), GGMLType.Q6_K: (256, 210),
     GGMLType.IQ4_NL: (32, 18), GGMLType.IQ4_XS: (256, 136),
+    GGMLType.IQ2_XXS: (256, 66), GGMLType.IQ2_XS: (256, 74), GGMLType.IQ2_S: (256, 82), GGMLType.IQ3_XXS: (256, 98),
+    GGMLType.IQ3_S: (256, 110), GGMLType.IQ1_S: (256, 50), GGMLType.IQ1_M: (256, 56),
 }
 
 WEIGHT_TYPES = [GGMLType.Q4_0, GGMLType.Q4_1, GGMLType.Q5_0, GGMLType.Q5_1, GGMLType.Q8_0,
                 GGMLType.Q2_K, GGMLType.Q3_K, GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K]
 # formats with dequantise + MMVQ kernels only (the reference's ggml_mul_mat_a8 has no case for them)
-IQ_TYPES = [GGMLType.IQ4_NL, GGMLType.IQ4_XS]
+IQ_TYPES = [GGMLType.IQ4_NL, GGMLType.IQ4_XS, GGMLType.IQ2_XXS, GGMLType.IQ2_XS, GGMLType.IQ2_S, GGMLType.IQ3_XXS,
+            GGMLType.IQ3_S, GGMLType.IQ1_S, GGMLType.IQ1_M]
 # formats whose MMQ activation scratch stores half2(d, sum) — mmq_need_sum, HK/ggml/mmq.cu:84-106
 NEED_SUM = {GGMLType.Q4_0, GGMLType.Q4_1, GGMLType.Q5_1, GGMLType.Q4_K, GGMLType.Q5_K}
 

@@ -15,7 +15,20 @@ _F16_FIELDS = {
     GGMLType.Q8_0: (0, None), GGMLType.Q2_K: (80, 82), GGMLType.Q3_K: (108, None),
     GGMLType.Q4_K: (0, 2), GGMLType.Q5_K: (0, 2), GGMLType.Q6_K: (208, None),
     GGMLType.IQ4_NL: (0, None), GGMLType.IQ4_XS: (0, None),
+    GGMLType.IQ2_XXS: (0, None), GGMLType.IQ2_XS: (0, None), GGMLType.IQ2_S: (0, None), GGMLType.IQ3_XXS: (0, None),
+    GGMLType.IQ3_S: (0, None), GGMLType.IQ1_S: (0, None),
+    GGMLType.IQ1_M: (None, None),   # no fp16 field: the super-block scale is scattered over the high nibbles of scales[]
 }
+
+
+def _iq1m_put_scale(b, d16):
+    """IQ1_M: write the fp16 super-block scale `d16` [n] into bits 12-15 of the four uint16 of scales[] (block bytes 48..55),
+    nibble k of the value into word k (HK/ggml/dequantize.cuh:481-482 reads it back as iq1m_scale_t)"""
+    u = d16.view(np.uint16).astype(np.uint16)
+    for k in range(4):
+        nib = ((u >> (4 * k)) & 0xF).astype(np.uint8)
+        b[:, 49 + 2 * k] = (b[:, 49 + 2 * k] & 0x0F) | (nib << 4)
+
 
 
 def random_blocks(t, n_blocks, seed=0, d_scale=1.0):
@@ -27,7 +40,10 @@ def random_blocks(t, n_blocks, seed=0, d_scale=1.0):
     b = rng.integers(0, 256, size=(n_blocks, bs), dtype=np.uint8)
     d_off, m_off = _F16_FIELDS[t]
     d = (rng.uniform(0.5, 2.0, n_blocks) * 2.0 ** -8 * d_scale).astype(np.float16)
-    b[:, d_off:d_off + 2] = d.view(np.uint8).reshape(n_blocks, 2)
+    if d_off is None:
+        _iq1m_put_scale(b, d)
+    else:
+        b[:, d_off:d_off + 2] = d.view(np.uint8).reshape(n_blocks, 2)
     if m_off is not None:
         m = (rng.uniform(-1.0, 1.0, n_blocks) * 2.0 ** -6 * d_scale).astype(np.float16)
         b[:, m_off:m_off + 2] = m.view(np.uint8).reshape(n_blocks, 2)
@@ -56,7 +72,10 @@ def edge_blocks(t):
         for d in specials:
             for m in (specials[[0, 2, 3, 8]] if m_off is not None else [None]):
                 blk = np.full(bs, fill, np.uint8)
-                blk[d_off:d_off + 2] = np.array([d], np.float16).view(np.uint8)
+                if d_off is None:
+                    _iq1m_put_scale(blk.reshape(1, -1), np.array([d], np.float16))
+                else:
+                    blk[d_off:d_off + 2] = np.array([d], np.float16).view(np.uint8)
                 if m is not None:
                     blk[m_off:m_off + 2] = np.array([m], np.float16).view(np.uint8)
                 out.append(blk)

@@ -10,8 +10,8 @@
  *   - `type` is the ggml type id (HK/ggml/ggml-common.h:1128-1161):
  *     Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8 Q2_K=10 Q3_K=11 Q4_K=12 Q5_K=13 Q6_K=14,
  *     and for dequantise + MMVQ only (as in the reference, whose ggml_mul_mat_a8 has no IQ case,
- *     HK/ggml/mmq.cu:222-251): IQ4_NL=20 IQ4_XS=23.  The other seven IQ ids of the reference's
- *     dispatch (16-19, 21, 22, 29: HK/ggml/ggml_kernel.cu:145-189) return GGQ_ERR_TYPE.
+ *     HK/ggml/mmq.cu:222-251) the nine IQ formats of its dispatch (HK/ggml/ggml_kernel.cu:145-189):
+ *     IQ2_XXS=16 IQ2_XS=17 IQ3_XXS=18 IQ1_S=19 IQ4_NL=20 IQ3_S=21 IQ2_S=22 IQ4_XS=23 IQ1_M=29.
  *   - W is the raw GGUF tensor payload: `n_rows` rows, each `k/qk` blocks,
  *     row-major, device memory for the ggq_* (GPU) calls.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
@@ -44,8 +44,16 @@ enum ggq_type {
   GGQ_TYPE_Q4_K = 12,
   GGQ_TYPE_Q5_K = 13,
   GGQ_TYPE_Q6_K = 14,
-  GGQ_TYPE_IQ4_NL = 20, /* dequantise + MMVQ only */
-  GGQ_TYPE_IQ4_XS = 23  /* dequantise + MMVQ only */
+  /* the IQ formats: dequantise + MMVQ only, as in the reference (HK/ggml/ggml_kernel.cu:145-189) */
+  GGQ_TYPE_IQ2_XXS = 16,
+  GGQ_TYPE_IQ2_XS = 17,
+  GGQ_TYPE_IQ3_XXS = 18,
+  GGQ_TYPE_IQ1_S = 19,
+  GGQ_TYPE_IQ4_NL = 20,
+  GGQ_TYPE_IQ3_S = 21,
+  GGQ_TYPE_IQ2_S = 22,
+  GGQ_TYPE_IQ4_XS = 23,
+  GGQ_TYPE_IQ1_M = 29
 };
 
 /* activation / output element types (HK/ggml/dispatch_utils.h:14-20) */

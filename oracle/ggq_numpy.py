@@ -23,14 +23,19 @@ import numpy as np
 Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 2, 3, 6, 7, 8, 9
 Q2_K, Q3_K, Q4_K, Q5_K, Q6_K = 10, 11, 12, 13, 14
 IQ4_NL, IQ4_XS = 20, 23
+IQ2_XXS, IQ2_XS, IQ3_XXS, IQ1_S, IQ3_S, IQ2_S, IQ1_M = 16, 17, 18, 19, 21, 22, 29
+GRID_IQ = (IQ2_XXS, IQ2_XS, IQ2_S, IQ3_XXS, IQ3_S)
 KVALUES_IQ4NL = np.array([-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113], np.int32)
 
 BLOCK_ELEMS = {Q4_0: 32, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_0: 32, Q8_1: 32,
-               Q2_K: 256, Q3_K: 256, Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ4_XS: 256}
+               Q2_K: 256, Q3_K: 256, Q4_K: 256, Q5_K: 256, Q6_K: 256, IQ4_NL: 32, IQ4_XS: 256,
+               IQ2_XXS: 256, IQ2_XS: 256, IQ2_S: 256, IQ3_XXS: 256, IQ3_S: 256, IQ1_S: 256, IQ1_M: 256}
 BLOCK_BYTES = {Q4_0: 18, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_0: 34, Q8_1: 36,
-               Q2_K: 84, Q3_K: 110, Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ4_XS: 136}
+               Q2_K: 84, Q3_K: 110, Q4_K: 144, Q5_K: 176, Q6_K: 210, IQ4_NL: 18, IQ4_XS: 136,
+               IQ2_XXS: 66, IQ2_XS: 74, IQ2_S: 82, IQ3_XXS: 98, IQ3_S: 110, IQ1_S: 50, IQ1_M: 56}
 NAMES = {Q4_0: "Q4_0", Q4_1: "Q4_1", Q5_0: "Q5_0", Q5_1: "Q5_1", Q8_0: "Q8_0",
-         Q2_K: "Q2_K", Q3_K: "Q3_K", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", IQ4_NL: "IQ4_NL", IQ4_XS: "IQ4_XS"}
+         Q2_K: "Q2_K", Q3_K: "Q3_K", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", IQ4_NL: "IQ4_NL", IQ4_XS: "IQ4_XS",
+         IQ2_XXS: "IQ2_XXS", IQ2_XS: "IQ2_XS", IQ2_S: "IQ2_S", IQ3_XXS: "IQ3_XXS", IQ3_S: "IQ3_S", IQ1_S: "IQ1_S", IQ1_M: "IQ1_M"}
 WEIGHT_TYPES = [Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K]
 
 
@@ -140,6 +145,129 @@ def iq4_codes(blocks, t):
     return KVALUES_IQ4NL[idx], (lo | (hi << 4)) - 32, _f16(b[:, 0:2])
 
 
+_GRIDS = None
+
+
+def iq_grids():
+    """the codebook grids as numpy arrays, read from the data header the kernels use (constant data transcribed from the
+    reference's HK/ggml/ggml-common.h:193-1011): name -> uint8 [n, 8 | 4] magnitudes (iq1s: uint32 [2048])"""
+    global _GRIDS
+    if _GRIDS is None:
+        import os
+        import re
+        here = os.path.dirname(os.path.abspath(__file__))
+        txt = open(os.path.join(here, "..", "ggml-libtorch_amd", "csrc", "hip", "iq_tables.h")).read()
+        g = {}
+        for m in re.finditer(r"ggq_(\w+)\[(\d+)\] = \{(.*?)\};", txt, re.S):
+            vals = [int(v.rstrip("ul"), 16) for v in re.findall(r"0x[0-9a-f]+u?l?l?", m.group(3))]
+            assert len(vals) == int(m.group(2))
+            a = np.array(vals, dtype=np.uint64)
+            if m.group(1).startswith("iq1s"):
+                g[m.group(1)] = a.astype(np.uint32)
+            else:
+                nbytes = 8 if m.group(1).startswith("iq2") else 4
+                g[m.group(1)] = ((a[:, None] >> (8 * np.arange(nbytes, dtype=np.uint64))) & np.uint64(0xFF)).astype(np.uint8)
+        _GRIDS = g
+    return _GRIDS
+
+
+def _ksigns(i7):
+    """ksigns_iq2xs: the 7-bit value with an 8th bit that makes the popcount even -> 8 sign bits"""
+    i7 = i7.astype(np.int64)
+    par = np.zeros_like(i7)
+    for b in range(7):
+        par ^= (i7 >> b) & 1
+    return i7 | (par << 7)
+
+
+def iq_grid_codes(blocks, t):
+    """IQ2_XXS / IQ2_XS / IQ2_S / IQ3_XXS / IQ3_S (block layouts HK/ggml/ggml-common.h:108-149), element order:
+    signed grid values int32 [nb, 256], the float scale factor of each 16 elements float32 [nb, 16] (0.5 + scale nibble),
+    the format's constant (0.25 | 0.5) and d [nb] — derived per field from the struct layouts, vectorised over blocks."""
+    b = as_blocks(blocks, t)
+    nb = b.shape[0]
+    G = iq_grids()
+    bi = b.astype(np.int64)
+    d = _f16(b[:, 0:2])
+    ib = np.arange(8)
+    if t == IQ2_XXS:      # per sub-block: 4 index bytes, then a uint32: 4 x 7 sign bits | scale << 28
+        sub = bi[:, 2:66].reshape(nb, 8, 8)
+        idx = sub[:, :, 0:4]
+        aux = sub[:, :, 4] | (sub[:, :, 5] << 8) | (sub[:, :, 6] << 16) | (sub[:, :, 7] << 24)
+        mag = G["iq2xxs_grid"][idx]                                          # [nb, 8, 4, 8]
+        sg = _ksigns((aux[:, :, None] >> (7 * np.arange(4))) & 127)           # [nb, 8, 4]
+        mul = np.repeat((0.5 + (aux >> 28)).astype(np.float32), 2, axis=1)    # per sub-block -> per 16
+        post = 0.25
+    elif t == IQ2_XS:     # uint16 qs[32]: 9-bit grid index | 7 sign bits; uint8 scales[8]: two nibbles per sub-block
+        q2 = (bi[:, 2:66:2] | (bi[:, 3:66:2] << 8)).reshape(nb, 8, 4)
+        mag = G["iq2xs_grid"][q2 & 511]
+        sg = _ksigns(q2 >> 9)
+        sc = bi[:, 66:74]
+        mul = (0.5 + np.stack([sc & 15, sc >> 4], axis=2).reshape(nb, 16)).astype(np.float32)
+        post = 0.25
+    elif t == IQ2_S:      # qs[0..31] low index bytes, qs[32..63] sign bytes, qh[8] two high index bits per run, scales[8]
+        lo = bi[:, 2:34].reshape(nb, 8, 4)
+        qh = bi[:, 66:74]
+        hi = (qh[:, :, None] >> (2 * np.arange(4))) & 3
+        mag = G["iq2s_grid"][lo | (hi << 8)]
+        sg = bi[:, 34:66].reshape(nb, 8, 4)
+        sc = bi[:, 74:82]
+        mul = (0.5 + np.stack([sc & 15, sc >> 4], axis=2).reshape(nb, 16)).astype(np.float32)
+        post = 0.25
+    elif t == IQ3_XXS:    # qs[0..63]: one grid index per 4 elements; then 8 x uint32: 4 x 7 sign bits | scale << 28
+        idx = bi[:, 2:66].reshape(nb, 8, 4, 2)
+        gas = bi[:, 66:98].reshape(nb, 8, 4)
+        aux = gas[:, :, 0] | (gas[:, :, 1] << 8) | (gas[:, :, 2] << 16) | (gas[:, :, 3] << 24)
+        mag = G["iq3xxs_grid"][idx].reshape(nb, 8, 4, 8)
+        sg = _ksigns((aux[:, :, None] >> (7 * np.arange(4))) & 127)
+        mul = np.repeat((0.5 + (aux >> 28)).astype(np.float32), 2, axis=1)
+        post = 0.5
+    else:                 # IQ3_S: qs[64] low index bytes, qh[8] one high bit per index, signs[32], scales[4] (nibble per sub-block)
+        lo = bi[:, 2:66].reshape(nb, 8, 8)
+        qh = bi[:, 66:74]
+        hi = (qh[:, :, None] >> np.arange(8)) & 1
+        mag = G["iq3xs_grid"][lo | (hi << 8)].reshape(nb, 8, 4, 8)
+        sg = bi[:, 74:106].reshape(nb, 8, 4)
+        sc = bi[:, 106:110]
+        nib = np.stack([sc & 15, sc >> 4], axis=2).reshape(nb, 8)
+        mul = np.repeat((0.5 + nib).astype(np.float32), 2, axis=1)
+        post = 0.5
+    neg = (sg[..., None] >> np.arange(8)) & 1                                 # [nb, 8, 4, 8]
+    vals = np.where(neg == 1, -mag.astype(np.int32), mag.astype(np.int32)).reshape(nb, 256)
+    return vals, mul, np.float32(post), d
+
+
+def iq1_codes(blocks, t):
+    """IQ1_S / IQ1_M (HK/ggml/ggml-common.h:151-174): q in {0,1,2} int32 [nb, 256], delta per 8 elements float32 [nb, 32]
+    (-1 +- 0.125), the integer scale 2 s + 1 per 16 elements int32 [nb, 16] and the fp16 super-block scale [nb]."""
+    b = as_blocks(blocks, t)
+    nb = b.shape[0]
+    bi = b.astype(np.int64)
+    grid = iq_grids()["iq1s_grid_gpu"].astype(np.int64)
+    il = np.arange(4)
+    if t == IQ1_S:
+        d = _f16(b[:, 0:2])
+        qs = bi[:, 2:34].reshape(nb, 8, 4)
+        qh = bi[:, 34:50:2] | (bi[:, 35:50:2] << 8)                           # [nb, 8]
+        idx = qs | (((qh[:, :, None] >> (3 * il)) & 7) << 8)
+        delta = np.where(qh & 0x8000, -1.125, -0.875).astype(np.float32)
+        delta = np.repeat(delta, 4, axis=1)
+        sc = np.repeat(2 * ((qh >> 12) & 7) + 1, 2, axis=1).astype(np.int32)
+    else:
+        qs = bi[:, 0:32].reshape(nb, 8, 4)
+        qh = bi[:, 32:48].reshape(nb, 8, 2)                                   # one byte per two runs
+        nibq = (qh[:, :, il // 2] >> (4 * (il % 2))) & 15                     # [nb, 8, 4]: 3 index bits + the delta bit
+        idx = qs | ((nibq & 7) << 8)
+        delta = np.where(nibq & 8, -1.125, -0.875).astype(np.float32).reshape(nb, 32)
+        sc16 = bi[:, 48:56:2] | (bi[:, 49:56:2] << 8)                         # [nb, 4] uint16
+        d = np.ascontiguousarray(((sc16[:, 0] >> 12) | ((sc16[:, 1] >> 8) & 0xF0) | ((sc16[:, 2] >> 4) & 0xF00) | (sc16[:, 3] & 0xF000)).astype(np.uint16)).view(np.float16)
+        i16 = np.arange(16)
+        sc = (2 * ((sc16[:, i16 // 4] >> (3 * (i16 % 4))) & 7) + 1).astype(np.int32)
+    g = grid[idx]                                                              # [nb, 8, 4]
+    q = np.concatenate([(g[..., None] >> (8 * np.arange(4))) & 15, (g[..., None] >> (8 * np.arange(4) + 4)) & 15], axis=-1)
+    return q.reshape(nb, 256).astype(np.int32), delta, sc, d
+
+
 def scales16(blocks, t):
     """(d, dmin_or_m, sc16, mn16): fp16 block scales and per-16-element integer scale/min.
     Legacy formats: sc16/mn16 are None."""
@@ -166,6 +294,12 @@ def dequantize_exact(blocks, t):
     if t in (IQ4_NL, IQ4_XS):
         v, ls, d = iq4_codes(blocks, t)
         return d.astype(np.float64)[:, None] * np.repeat(ls, 32, axis=1) * v
+    if t in GRID_IQ:
+        v, mul, post, d = iq_grid_codes(blocks, t)
+        return d.astype(np.float64)[:, None] * np.repeat(mul, 16, axis=1).astype(np.float64) * float(post) * v
+    if t in (IQ1_S, IQ1_M):
+        q, delta, sc, d = iq1_codes(blocks, t)
+        return d.astype(np.float64)[:, None] * np.repeat(sc, 16, axis=1) * (q + np.repeat(delta, 8, axis=1).astype(np.float64))
     q = unpack_ints(blocks, t).astype(np.float64)
     d, m, sc, mn = scales16(blocks, t)
     d = d.astype(np.float64)[:, None]
@@ -190,6 +324,12 @@ def gguf_dequantize(blocks, t):
         v, ls, dd = iq4_codes(blocks, t)
         dl = dd.astype(f32)[:, None] * np.repeat(ls, 32, axis=1).astype(f32) if t == IQ4_XS else dd.astype(f32)[:, None]
         return dl * v.astype(f32)
+    if t in GRID_IQ:   # gguf-py: db = d * (0.5 + scales) * 0.25 | 0.5; db * grid * signs
+        v, mul, post, dd = iq_grid_codes(blocks, t)
+        return (dd.astype(f32)[:, None] * np.repeat(mul, 16, axis=1) * post) * v.astype(f32)
+    if t in (IQ1_S, IQ1_M):   # gguf-py: dl = d * (2 * scale + 1); dl * (grid + delta)
+        qq, delta, sc1, dd = iq1_codes(blocks, t)
+        return (dd.astype(f32)[:, None] * np.repeat(sc1, 16, axis=1).astype(f32)) * (qq.astype(f32) + np.repeat(delta, 8, axis=1))
     q = unpack_ints(blocks, t)
     d, m, sc, mn = scales16(blocks, t)
     d = d.astype(f32)[:, None]
@@ -228,6 +368,16 @@ def dequantize_f16(blocks, t):
         with np.errstate(all="ignore"):
             dl = d.astype(np.float32)[:, None] * np.repeat(ls, 32, axis=1).astype(np.float32) if t == IQ4_XS else d.astype(np.float32)[:, None]
             return (dl * v.astype(np.float32)).astype(h)
+    if t in GRID_IQ:   # fp32: ((half2float(d) * (0.5f + s)) * post) * grid * (+-1), one rounding to fp16 (dequantize.cuh:256-352)
+        v, mul, post, d = iq_grid_codes(blocks, t)
+        with np.errstate(all="ignore"):
+            dd = (d.astype(np.float32)[:, None] * np.repeat(mul, 16, axis=1)) * post
+            return (dd * v.astype(np.float32)).astype(h)
+    if t in (IQ1_S, IQ1_M):   # fp32: d * (q + delta), d = half2float(d) * (2 s + 1) (dequantize.cuh:354-398)
+        q, delta, sc, d = iq1_codes(blocks, t)
+        with np.errstate(all="ignore"):
+            dd = d.astype(np.float32)[:, None] * np.repeat(sc, 16, axis=1).astype(np.float32)
+            return (dd * (q.astype(np.float32) + np.repeat(delta, 8, axis=1))).astype(h)
     q = unpack_ints(blocks, t)
     d, m, sc, mn = scales16(blocks, t)
     d = d[:, None]

@@ -91,7 +91,78 @@ static inline uint32_t rd32(const uint8_t* p) {
 
 enum { T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9,
        T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14,
-       T_IQ4_NL = 20, T_IQ4_XS = 23 /* HK/ggml/ggml-common.h:1149, 1152 */ };
+       T_IQ2_XXS = 16, T_IQ2_XS = 17, T_IQ3_XXS = 18, T_IQ1_S = 19, T_IQ4_NL = 20, T_IQ3_S = 21, T_IQ2_S = 22,
+       T_IQ4_XS = 23, T_IQ1_M = 29 /* HK/ggml/ggml-common.h:1145-1158 */ };
+
+/* the codebook grids: constant data shared with the kernels (transcribed from HK/ggml/ggml-common.h:193-1011) */
+#include "../ggml-libtorch_amd/csrc/hip/iq_tables.h"
+#define IQ1_DELTA 0.125f /* IQ1S_DELTA = IQ1M_DELTA, ggml-common.h:752-753 */
+/* ksigns_iq2xs[i] (ggml-common.h:1013-1022): i with bit 7 set so that the popcount is even; kmask_iq2xs[j] = 1 << j */
+static inline int iq_ksigns(int i) { int p = 0; for (int b = 0; b < 7; ++b) p ^= (i >> b) & 1; return i | (p << 7); }
+static inline int is_grid_iq(int type) {
+  return type == T_IQ2_XXS || type == T_IQ2_XS || type == T_IQ2_S || type == T_IQ3_XXS || type == T_IQ3_S;
+}
+/* One 8-element run (il of sub-block ib) of a grid-codebook block: unsigned magnitudes g[8], sign bits, and the float
+ * scale factor the reference multiplies half2float(d) with — dequantize.cuh:256-352 / vecdotq.cuh:607-748 */
+static void iq_run(int type, const uint8_t* b, int ib, int il, uint8_t g[8], int* signs, float* mul, float* post) {
+  switch (type) {
+    case T_IQ2_XXS: { /* {half d; uint16 qs[32]}: per sub-block 4 index bytes + uint32 (4 x 7 sign bits, scale << 28) */
+      const uint8_t* q2 = b + 2 + 8 * ib;
+      const uint32_t aux32 = rd32(q2 + 4);
+      const uint64_t gr = ggq_iq2xxs_grid[q2[il]];
+      for (int j = 0; j < 8; ++j) g[j] = (uint8_t)(gr >> (8 * j));
+      *signs = iq_ksigns((aux32 >> (7 * il)) & 127); *mul = 0.5f + (float)(aux32 >> 28); *post = 0.25f;
+    } break;
+    case T_IQ2_XS: { /* {half d; uint16 qs[32]; uint8 scales[8]} */
+      const uint16_t q2 = rd16(b + 2 + 8 * ib + 2 * il);
+      const uint64_t gr = ggq_iq2xs_grid[q2 & 511];
+      for (int j = 0; j < 8; ++j) g[j] = (uint8_t)(gr >> (8 * j));
+      *signs = iq_ksigns(q2 >> 9); *mul = 0.5f + (float)((b[66 + ib] >> (4 * (il / 2))) & 0xf); *post = 0.25f;
+    } break;
+    case T_IQ2_S: { /* {half d; uint8 qs[64]; uint8 qh[8]; uint8 scales[8]}: qs[32..63] are the sign bytes */
+      const uint64_t gr = ggq_iq2s_grid[b[2 + 4 * ib + il] | ((b[66 + ib] << (8 - 2 * il)) & 0x300)];
+      for (int j = 0; j < 8; ++j) g[j] = (uint8_t)(gr >> (8 * j));
+      *signs = b[2 + 32 + 4 * ib + il]; *mul = 0.5f + (float)((b[74 + ib] >> (4 * (il / 2))) & 0xf); *post = 0.25f;
+    } break;
+    case T_IQ3_XXS: { /* {half d; uint8 qs[96]}: 64 grid indices, then 8 x uint32 (signs + scale) */
+      const uint8_t* q3 = b + 2 + 8 * ib;
+      const uint32_t aux32 = rd32(b + 2 + 64 + 4 * ib);
+      const uint32_t g1 = ggq_iq3xxs_grid[q3[2 * il]], g2 = ggq_iq3xxs_grid[q3[2 * il + 1]];
+      for (int j = 0; j < 4; ++j) { g[j] = (uint8_t)(g1 >> (8 * j)); g[4 + j] = (uint8_t)(g2 >> (8 * j)); }
+      *signs = iq_ksigns((aux32 >> (7 * il)) & 127); *mul = 0.5f + (float)(aux32 >> 28); *post = 0.5f;
+    } break;
+    default: { /* T_IQ3_S: {half d; uint8 qs[64]; qh[8]; signs[32]; scales[4]} */
+      const uint8_t* qs = b + 2 + 8 * ib;
+      const int qh = b[66 + ib];
+      const uint32_t g1 = ggq_iq3xs_grid[qs[2 * il] | ((qh << (8 - 2 * il)) & 256)];
+      const uint32_t g2 = ggq_iq3xs_grid[qs[2 * il + 1] | ((qh << (7 - 2 * il)) & 256)];
+      for (int j = 0; j < 4; ++j) { g[j] = (uint8_t)(g1 >> (8 * j)); g[4 + j] = (uint8_t)(g2 >> (8 * j)); }
+      *signs = b[74 + 4 * ib + il]; *mul = 0.5f + (float)((b[106 + ib / 2] >> (4 * (ib % 2))) & 0xf); *post = 0.5f;
+    } break;
+  }
+}
+/* IQ1_S / IQ1_M run: nibble values q[8] (0..2), delta, and the sub-block scale d (dequantize.cuh:354-398) */
+static float iq1m_scale(const uint8_t* b) { /* iq1m_scale_t: the fp16 super-block scale scattered over scales[] */
+  const uint16_t sc0 = rd16(b + 48), sc1 = rd16(b + 50), sc2 = rd16(b + 52), sc3 = rd16(b + 54);
+  return H((uint16_t)((sc0 >> 12) | ((sc1 >> 8) & 0x00f0) | ((sc2 >> 4) & 0x0f00) | (sc3 & 0xf000)));
+}
+static void iq1_run(int type, const uint8_t* b, int ib, int il, int q[8], float* delta, float* d) {
+  uint32_t grid;
+  if (type == T_IQ1_S) { /* {half d; uint8 qs[32]; uint16 qh[8]} */
+    const uint16_t qh = rd16(b + 34 + 2 * ib);
+    *delta = (qh & 0x8000) ? -1 - IQ1_DELTA : -1 + IQ1_DELTA;
+    *d = H(rd16(b)) * (2 * ((qh >> 12) & 7) + 1);
+    grid = ggq_iq1s_grid_gpu[b[2 + 4 * ib + il] | (((qh >> (3 * il)) & 7) << 8)];
+  } else { /* T_IQ1_M: {uint8 qs[32]; uint8 qh[16]; uint8 scales[8]} */
+    const int ib16 = 2 * ib + il / 2;
+    const uint16_t sc = rd16(b + 48 + 2 * (ib16 / 4));
+    const int qh = b[32 + 2 * ib + il / 2];
+    *d = iq1m_scale(b) * (2 * ((sc >> (3 * (ib16 % 4))) & 0x7) + 1);
+    *delta = (qh & (0x08 << (4 * (il % 2)))) ? -1 - IQ1_DELTA : -1 + IQ1_DELTA;
+    grid = ggq_iq1s_grid_gpu[b[4 * ib + il] | (((qh >> (4 * (il % 2))) & 7) << 8)];
+  }
+  for (int j = 0; j < 4; ++j) { q[j] = (int8_t)((grid >> (8 * j)) & 0x0f); q[4 + j] = (int8_t)((grid >> (8 * j + 4)) & 0x0f); }
+}
 
 /* non-linear 4-bit codebook, HK/ggml/ggml-common.h:1060 */
 static const int8_t kvalues_iq4nl[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
@@ -112,6 +183,7 @@ int oracle_block_elems(int type) {
   switch (type) {
     case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_0: case T_Q8_1: case T_IQ4_NL: return 32;
     case T_Q2_K: case T_Q3_K: case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_IQ4_XS: return 256;
+    case T_IQ2_XXS: case T_IQ2_XS: case T_IQ2_S: case T_IQ3_XXS: case T_IQ3_S: case T_IQ1_S: case T_IQ1_M: return 256;
     default: return 0;
   }
 }
@@ -122,6 +194,8 @@ int oracle_block_bytes(int type) {
     case T_Q2_K: return 84; case T_Q3_K: return 110; case T_Q4_K: return 144;
     case T_Q5_K: return 176; case T_Q6_K: return 210;
     case T_IQ4_NL: return 18; case T_IQ4_XS: return 136;
+    case T_IQ2_XXS: return 66; case T_IQ2_XS: return 74; case T_IQ2_S: return 82; case T_IQ3_XXS: return 98;
+    case T_IQ3_S: return 110; case T_IQ1_S: return 50; case T_IQ1_M: return 56;
     default: return 0;
   }
 }
@@ -271,6 +345,30 @@ static int q3k_scale(const uint8_t* sc, int is) {
 int oracle_dequantize_row_f16(int type, const void* vw, uint16_t* y, int64_t k) {
   const uint8_t* w = (const uint8_t*)vw;
   const h16 h8 = oracle_f32_to_f16(8.0f), h16_ = oracle_f32_to_f16(16.0f);
+  if (is_grid_iq(type)) { /* dequantize.cuh:256-352: y = __float2half(d * grid[j] * (+-1.f)), d = half2float(x.d) * (0.5f + s) * post */
+    const int bs = oracle_block_bytes(type);
+    for (int64_t i = 0; i < k / 256; i++)
+      for (int ib = 0; ib < 8; ++ib)
+        for (int il = 0; il < 4; ++il) {
+          const uint8_t* b = w + i * bs;
+          uint8_t g[8]; int signs; float mul, post;
+          iq_run(type, b, ib, il, g, &signs, &mul, &post);
+          const float d = H(rd16(b)) * mul * post;
+          for (int j = 0; j < 8; ++j) y[i * 256 + 32 * ib + 8 * il + j] = oracle_f32_to_f16(d * g[j] * ((signs >> j) & 1 ? -1.f : 1.f));
+        }
+    return 0;
+  }
+  if (type == T_IQ1_S || type == T_IQ1_M) { /* dequantize.cuh:354-398: y = __float2half(d * (q[j] + delta)) */
+    const int bs = oracle_block_bytes(type);
+    for (int64_t i = 0; i < k / 256; i++)
+      for (int ib = 0; ib < 8; ++ib)
+        for (int il = 0; il < 4; ++il) {
+          int q[8]; float delta, d;
+          iq1_run(type, w + i * bs, ib, il, q, &delta, &d);
+          for (int j = 0; j < 8; ++j) y[i * 256 + 32 * ib + 8 * il + j] = oracle_f32_to_f16(d * (q[j] + delta));
+        }
+    return 0;
+  }
   switch (type) {
     case T_IQ4_NL: /* dequantize.cuh:399-416: fp32 product d * kvalues, one rounding to fp16 */
       for (int64_t i = 0; i < k / 32; i++) {
@@ -551,6 +649,25 @@ int oracle_dequantize_row_f64(int type, const void* vw, double* y, int64_t k) {
   int qv[256], sc16[16], mn16[16];
   for (int64_t i = 0; i < k / qk; ++i) {
     const uint8_t* b = w + i * bs;
+    if (is_grid_iq(type)) {
+      for (int ib = 0; ib < 8; ++ib)
+        for (int il = 0; il < 4; ++il) {
+          uint8_t g[8]; int signs; float mul, post;
+          iq_run(type, b, ib, il, g, &signs, &mul, &post);
+          const double d = (double)H(rd16(b)) * mul * post;
+          for (int j = 0; j < 8; ++j) y[i * 256 + 32 * ib + 8 * il + j] = d * g[j] * ((signs >> j) & 1 ? -1.0 : 1.0);
+        }
+      continue;
+    }
+    if (type == T_IQ1_S || type == T_IQ1_M) {
+      for (int ib = 0; ib < 8; ++ib)
+        for (int il = 0; il < 4; ++il) {
+          int q[8]; float delta, d;
+          iq1_run(type, b, ib, il, q, &delta, &d);   /* d = half * odd integer <= 15: exact in fp32 */
+          for (int j = 0; j < 8; ++j) y[i * 256 + 32 * ib + 8 * il + j] = (double)d * ((double)q[j] + (double)delta);
+        }
+      continue;
+    }
     if (type == T_IQ4_NL) {
       const double d = H(rd16(b));
       for (int j = 0; j < 16; ++j) {
@@ -667,6 +784,54 @@ static inline float q8s(const uint8_t* q8, int blk) { return H(rd16(q8 + blk * 3
 
 /* vec_dot_<fmt>_q8_1(block, q8 blocks aligned with it, iqs) — one lane's contribution */
 static float vec_dot_mmvq(int type, const uint8_t* b, const uint8_t* q8, int iqs) {
+  if (is_grid_iq(type)) { /* vecdotq.cuh:607-748: iqs = 32-element sub-block */
+    const int ib32 = iqs;
+    const int8_t* q8v = q8qs(q8, ib32);
+    int sumi[2] = {0, 0};
+    float mul[2] = {0, 0}, post = 0;
+    for (int l = 0; l < 4; ++l) {
+      uint8_t g[8]; int signs;
+      iq_run(type, b, ib32, l, g, &signs, &mul[l / 2], &post);
+      for (int j = 0; j < 8; ++j) sumi[l / 2] += q8v[8 * l + j] * g[j] * ((signs >> j) & 1 ? -1 : 1);
+    }
+    if (type == T_IQ2_XS || type == T_IQ2_S) { /* :631-700: d * ((0.5f + ls1) * sumi1 + (0.5f + ls2) * sumi2) */
+      const float d = H(rd16(b)) * q8d(q8, ib32) * post;
+      return d * (mul[0] * sumi[0] + mul[1] * sumi[1]);
+    }
+    const float d = H(rd16(b)) * mul[0] * q8d(q8, ib32) * post; /* :607-629, 702-748 */
+    return d * (sumi[0] + sumi[1]);
+  }
+  if (type == T_IQ1_S) { /* vecdotq.cuh:750-781 */
+    const uint16_t qh = rd16(b + 34 + 2 * iqs);
+    const int8_t* q8v = q8qs(q8, iqs);
+    int sumi = 0;
+    for (int l = 0; l < 4; ++l) {
+      int q[8]; float dl, dd;
+      iq1_run(type, b, iqs, l, q, &dl, &dd);
+      for (int j = 0; j < 8; ++j) sumi += q8v[8 * l + j] * q[j];
+    }
+    const float d1q = H(rd16(b)) * (((qh >> 11) & 0x0E) + 1);
+    const float delta = -1.0f + IQ1_DELTA - (qh & 0x8000) * (2.0f * IQ1_DELTA / 0x8000);
+    return d1q * (q8d(q8, iqs) * sumi + q8s(q8, iqs) * delta);
+  }
+  if (type == T_IQ1_M) { /* vecdotq.cuh:783-826 */
+    const int8_t* q8v = q8qs(q8, iqs);
+    int sumi[2] = {0, 0};
+    float sumf[2] = {0.0f, 0.0f};
+    for (int l = 0; l < 4; ++l) {
+      int q[8]; float dl, dd;
+      iq1_run(type, b, iqs, l, q, &dl, &dd);
+      const int qhl = b[32 + 2 * iqs + l / 2] >> (4 * (l % 2));
+      const float delta = -1.0f + IQ1_DELTA - (qhl & 0x08) * (2.0f * IQ1_DELTA / 0x08);
+      int sumy = 0;
+      for (int j = 0; j < 8; ++j) { sumi[l / 2] += q8v[8 * l + j] * q[j]; sumy += q8v[8 * l + j]; }
+      sumf[l / 2] += delta * sumy;
+    }
+    const float d = iq1m_scale(b) * q8d(q8, iqs);
+    const int tmp = rd16(b + 48 + 2 * (iqs / 2)) >> (6 * (iqs % 2));
+    const int sc0 = 2 * ((tmp >> 0) & 0x07) + 1, sc1 = 2 * ((tmp >> 3) & 0x07) + 1;
+    return d * ((sumi[0] + sumf[0]) * sc0 + (sumi[1] + sumf[1]) * sc1);
+  }
   switch (type) {
     case T_IQ4_NL: { /* vecdotq.cuh:842-864: codebook bytes (get_int_from_table_16, :828-840) x q8, vdr = 2 */
       int sumi1 = 0, sumi2 = 0;
@@ -859,6 +1024,7 @@ static int mmvq_qi(int type) {
   switch (type) {
     case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_IQ4_NL: return 4;   /* QI4_NL, ggml-common.h:178 */
     case T_Q8_0: case T_IQ4_XS: return 8;                                        /* QI4_XS, ggml-common.h:185 */
+    case T_IQ2_XXS: case T_IQ2_XS: case T_IQ2_S: case T_IQ3_XXS: case T_IQ3_S: case T_IQ1_S: case T_IQ1_M: return 8; /* QK_K / (4 * 8) */
     case T_Q2_K: case T_Q3_K: return 16;
     case T_Q4_K: case T_Q5_K: case T_Q6_K: return 32;
     default: return 0;
@@ -867,6 +1033,7 @@ static int mmvq_qi(int type) {
 static int mmvq_vdr(int type) {
   switch (type) {
     case T_Q2_K: case T_Q3_K: case T_Q6_K: case T_IQ4_XS: return 1;   /* mmvq.cuh:198: vdr 1 */
+    case T_IQ2_XXS: case T_IQ2_XS: case T_IQ2_S: case T_IQ3_XXS: case T_IQ3_S: case T_IQ1_S: case T_IQ1_M: return 1; /* mmvq.cuh:130-209 */
     default: return 2;                                                 /* IQ4_NL: VDR_Q4_0_Q8_1_MMVQ, mmvq.cuh:189 */
   }
 }
@@ -936,7 +1103,7 @@ static int idot(const int* a, const int8_t* b, int n) {
 
 int oracle_mul_mat_q(int type, const void* vw, const void* vq8, float* y, float* yabs,
                      int64_t batch, int64_t k, int64_t n_rows) {
-  if (type == T_IQ4_NL || type == T_IQ4_XS) return -1; /* the reference's ggml_mul_mat_a8 has no IQ case (mmq.cu:222-251) */
+  if ((type >= T_IQ2_XXS && type <= T_IQ4_XS) || type == T_IQ1_M) return -1; /* the reference's ggml_mul_mat_a8 has no IQ case (mmq.cu:222-251) */
   const int qk = oracle_block_elems(type), bs = oracle_block_bytes(type);
   if (!qk || type == T_Q8_1 || k % qk) return -1;
   const uint8_t* w = (const uint8_t*)vw;

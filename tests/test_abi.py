@@ -47,7 +47,7 @@ def test_traits_match_format_table():
     for t in IQ_TYPES:   # dequantise + MMVQ only, like the reference (its ggml_mul_mat_a8 switch has no IQ case)
         assert L.ggq_type_supported(int(t)) == 1 and L.ggq_mmq_type_supported(int(t)) == 0
         assert L.ggq_mmq_tiled_supported(int(t), 4096) == 0
-    for bad in (0, 1, 4, 5, 9, 15, 16, 17, 18, 19, 21, 22, 29, -1):   # incl. the seven IQ ids not built yet
+    for bad in (0, 1, 4, 5, 9, 15, 24, 28, 30, -1):
         assert L.ggq_type_supported(bad) == 0 and L.ggq_mmq_type_supported(bad) == 0
     assert L.ggq_row_bytes(int(GGMLType.Q4_K), 100) == -2 and L.ggq_row_bytes(99, 256) == -1
 

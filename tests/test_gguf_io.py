@@ -74,7 +74,7 @@ def test_reader_rejects_malformed_files(tmp_path):
     with pytest.raises(ValueError, match="out of bounds"):
         gguf_io.GGUFReader(p)
     # unsupported tensor type (IQ formats are out of scope)
-    head = struct.pack("<IIQQ", 0x46554747, 3, 1, 0) + _s("w") + struct.pack("<IQQIQ", 2, 256, 1, 16, 0)
+    head = struct.pack("<IIQQ", 0x46554747, 3, 1, 0) + _s("w") + struct.pack("<IQQIQ", 2, 256, 1, 24, 0)
     p.write_bytes(head + b"\0" * 4096)
     with pytest.raises(ValueError, match="outside the supported set"):
         gguf_io.GGUFReader(p)
