@@ -20,8 +20,9 @@
 // Q4_K runs at 72-75 % of the 8 TB/s roof; streamed from HBM with 4 distinct 90 MB outputs ("cold") at 60 % (48 % with
 // one chunk per thread), Q8_0 at 66 %.  On the same box a plain device copy of 86 MB reaches 5.1 TB/s (64 %) cold, a
 // fill 6.2 TB/s, and a kernel with this traffic mix and no arithmetic 5.2-5.7 TB/s (scripts/ubench_expand.hip).
-// Tried for the cold case without gain: nontemporal stores (+-0), two ADJACENT chunks per thread (49 -> 40 %: a lane's
-// stores are then 32 bytes apart), a grid-stride loop that touches the next chunk's bytes one iteration ahead (45 %).
+// Round 3: nontemporal stores for the output (see the store below): Q4_K 70.6 % cold / 86.7 % warm.
+// Tried for the cold case without gain: two ADJACENT chunks per thread (49 -> 40 %: a lane's stores are then 32 bytes
+// apart), a grid-stride loop that touches the next chunk's bytes one iteration ahead (45 %).
 #include "ggq_common.h"
 #include "iq_common.h"
 
@@ -338,7 +339,13 @@ __global__ void __launch_bounds__(256) dequant_kernel(const uint8_t* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < CH; ++i)
-    if (c0 + i * 256 < n_chunks) *(h8*)(out + (c0 + i * 256) * 8) = v[i];
+    if (c0 + i * 256 < n_chunks) {
+      // nontemporal: the 90 MB of fp16 output are written once and not re-read by this kernel — kept out of L2 they stop
+      // evicting the input stream (round 3, scripts/sweep_dequant.py: Q4_K 24.3 -> 20.5 us cold = 59.5 -> 70.6 % of the
+      // 8 TB/s roof, 19.4 -> 16.7 us warm; Q4_0 61.9 -> 72.7 % cold; round 2 had measured this as "+-0" on the
+      // one-chunk-per-thread form)
+      __builtin_nontemporal_store(v[i], (h8*)(out + (c0 + i * 256) * 8));
+    }
 
 }
 
