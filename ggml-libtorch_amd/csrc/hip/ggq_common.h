@@ -34,11 +34,22 @@ struct __attribute__((packed, aligned(2))) u32x2_a2 { uint32_t v[2]; };
 struct __attribute__((packed, aligned(2))) u32x3_a2 { uint32_t v[3]; };
 struct __attribute__((packed, aligned(2))) u32x4_a2 { uint32_t v[4]; };
 
+typedef uint32_t u32x4_al2 __attribute__((ext_vector_type(4), aligned(2)));
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return ((const u16x1_a2*)p)->v; }
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return ((const u32x1_a2*)p)->v; }
 __device__ __forceinline__ u32x2_a2 ld_u32x2(const uint8_t* p) { return *(const u32x2_a2*)p; }
 __device__ __forceinline__ u32x3_a2 ld_u32x3(const uint8_t* p) { return *(const u32x3_a2*)p; }
 __device__ __forceinline__ u32x4_a2 ld_u32x4(const uint8_t* p) { return *(const u32x4_a2*)p; }
+// the same load with the nontemporal hint, for weight bytes a kernel reads exactly ONCE per launch (the GEMV's quant
+// payload): they do not displace what is re-read (block headers, activations) from L2.  Measured round 3 with the
+// weights streamed from HBM (scripts/sweep_mmvq.py): Q4_0 9.33 -> 8.58 us, Q8_0 14.9 -> 13.9; replayed on ONE resident
+// tensor it costs 1 - 22 % (Q8_0 9.97 -> 12.2): the hint gives up what a back-to-back replay of the same 25 - 48 MB gains
+// from the Infinity Cache, which a model larger than that cache never sees.  Used for the 32-element block formats only:
+// for Q4_K / Q5_K (payload-only hint, headers re-read by eight units) it measured worse in both states (9.79 -> 10.06 cold).
+__device__ __forceinline__ u32x4_a2 ld_u32x4_stream(const uint8_t* p) {
+  const u32x4_al2 t = __builtin_nontemporal_load((const u32x4_al2*)p);
+  return u32x4_a2{{t[0], t[1], t[2], t[3]}};
+}
 
 __device__ __forceinline__ _Float16 bits_h(uint32_t b) {
   uint16_t s = (uint16_t)b;

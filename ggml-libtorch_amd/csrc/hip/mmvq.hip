@@ -76,7 +76,7 @@ template <> struct UnitDot<GGQ_TYPE_Q4_0> {  // vecdotq.cuh:45-65, 347-363
   struct Raw { uint32_t d; u32x4_a2 q; };
   static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 18;
-    return Raw{ld_u16(b), ld_u32x4(b + off::Q4_0_QS)};
+    return Raw{ld_u16(b), ld_u32x4_stream(b + off::Q4_0_QS)};
   }
   static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
   static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
@@ -95,7 +95,7 @@ template <> struct UnitDot<GGQ_TYPE_Q4_1> {  // vecdotq.cuh:69-91, 365-381
   struct Raw { uint32_t dm; u32x4_a2 q; };
   static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 20;
-    return Raw{ld_u32(b), ld_u32x4(b + off::Q4_1_QS)};
+    return Raw{ld_u32(b), ld_u32x4_stream(b + off::Q4_1_QS)};
   }
   static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
   static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
@@ -116,7 +116,7 @@ template <> struct UnitDot<GGQ_TYPE_Q5_0> {  // vecdotq.cuh:95-124, 383-401
   struct Raw { uint32_t d, qh; u32x4_a2 q; };
   static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 22;
-    return Raw{ld_u16(b), ld_u32(b + off::Q5_0_QH), ld_u32x4(b + off::Q5_0_QS)};
+    return Raw{ld_u16(b), ld_u32(b + off::Q5_0_QH), ld_u32x4_stream(b + off::Q5_0_QS)};
   }
   static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
   static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
@@ -139,7 +139,7 @@ template <> struct UnitDot<GGQ_TYPE_Q5_1> {  // vecdotq.cuh:128-158, 403-421
   struct Raw { uint32_t dm, qh; u32x4_a2 q; };
   static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 24;
-    return Raw{ld_u32(b), ld_u32(b + off::Q5_1_QH), ld_u32x4(b + off::Q5_1_QS)};
+    return Raw{ld_u32(b), ld_u32(b + off::Q5_1_QH), ld_u32x4_stream(b + off::Q5_1_QS)};
   }
   static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
   static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
@@ -163,7 +163,7 @@ template <> struct UnitDot<GGQ_TYPE_Q8_0> {  // vecdotq.cuh:162-174, 423-438
   struct Raw { uint32_t d; u32x4_a2 q0, q1; };
   static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 34;
-    return Raw{ld_u16(b), ld_u32x4(b + off::Q8_0_QS), ld_u32x4(b + off::Q8_0_QS + 16)};
+    return Raw{ld_u16(b), ld_u32x4_stream(b + off::Q8_0_QS), ld_u32x4_stream(b + off::Q8_0_QS + 16)};
   }
   static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
   static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
@@ -340,7 +340,7 @@ template <> struct UnitDot<GGQ_TYPE_IQ4_NL> {
   struct Raw { uint32_t d; u32x4_a2 q; };
   static __device__ __forceinline__ Raw load(const uint8_t* row, int u) {
     const uint8_t* b = row + (int64_t)u * 18;
-    return Raw{ld_u16(b), ld_u32x4(b + off::IQ4_NL_QS)};
+    return Raw{ld_u16(b), ld_u32x4_stream(b + off::IQ4_NL_QS)};
   }
   static __device__ __forceinline__ float run(const uint8_t* row, int u, const ActLds& A) { return dot(load(row, u), u, A); }
   static __device__ __forceinline__ float dot(const Raw& R, int u, const ActLds& A) {
