@@ -167,6 +167,25 @@ def cpu_baseline(sample_rows=N_DIM):
         dtT = time.perf_counter() - t0
         out["threads"] = {"value": round(nbytes / dtT / 1e9, 4), "unit": "GB/s", "cores": len(spans),
                           "sample": f"the same rows partitioned over {len(spans)} threads, {dtT:.2f} s"}
+    # the strongest host implementation we have: the product's CPU twin (ggq_cpu_mul_mat_q: AVX-512 VNNI / AVX2 byte dots,
+    # the same float sequence), checked here bit for bit against the oracle's output above
+    try:
+        from ggq import lib as ggqlib
+        C = ggqlib.cpu()
+        simd = C.ggq_cpu_mmq_simd_name().decode()
+        y2 = np.empty((BATCH, sample_rows), np.float32)
+        for nt in sorted({1, T}):
+            y2[:] = np.nan
+            t0 = time.perf_counter()
+            rc = C.ggq_cpu_mul_mat_q(O._p(w), O._p(q8), O._p(y2), Q4_K, BATCH, K_DIM, sample_rows, nt, 1)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            out[f"simd_twin_{nt}_threads"] = {
+                "value": round(nbytes / dt / 1e9, 4), "unit": "GB/s", "cores": nt, "kind": "product (ggq_cpu_mul_mat_q)",
+                "simd": simd, "bit_identical_to_oracle": bool(np.array_equal(y.view(np.uint32), y2.view(np.uint32))),
+                "sample": f"the same {sample_rows} rows x {BATCH} tokens, {dt * 1e3:.1f} ms"}
+    except Exception as e:  # pragma: no cover
+        out["simd_twin"] = {"error": str(e)[:200]}
     return out
 
 

@@ -97,9 +97,10 @@ def build_hip(force=False, verbose=False):
 def build_cpu(force=False):
     os.makedirs(LIB, exist_ok=True)
     src = os.path.join(CSRC, "cpu", "ggq_cpu.cpp")
+    src2 = os.path.join(CSRC, "cpu", "ggq_cpu_mmq.cpp")
     so = os.path.join(LIB, "libggq_cpu.so")
-    if force or _stale(so, [src, TRAITS_SRC, os.path.join(INCLUDE, "ggq.h")]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-o", so, src,
+    if force or _stale(so, [src, src2, TRAITS_SRC, os.path.join(INCLUDE, "ggq.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-o", so, src, src2,
               TRAITS_SRC])
     return so
 

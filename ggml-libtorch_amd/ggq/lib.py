@@ -56,6 +56,9 @@ CPU_SYMBOLS = {
     "ggq_cpu_dequantize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int]),
     "ggq_cpu_dequantize_f32_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int]),
     "ggq_cpu_simd_name": (ctypes.c_char_p, []),
+    "ggq_cpu_quantize_q8_1_mmq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int]),
+    "ggq_cpu_mul_mat_q": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int]),
+    "ggq_cpu_mmq_simd_name": (ctypes.c_char_p, []),
 }
 
 _hip = None

@@ -220,6 +220,17 @@ int ggq_cpu_dequantize_f32_ex(const void* w, float* out, int type, int64_t m, in
                               int nthreads, int simd);
 const char* ggq_cpu_simd_name(void);
 
+/* Host twin of the quantised GEMM for Q4_K, Q4_0 and Q8_0 (the reference has no CPU matmul: its ggml-cpu op only
+ * dequantises, ggml-cpu/custom_ops.cpp:16-34; this is the host baseline of the headline metric).  Same arithmetic as the GPU
+ * path's canon: ggq_cpu_quantize_q8_1_mmq = quantize_mmq_q8_1 (HK/ggml/mmq.cu:109-154; q: block_q8_1_mmq layout,
+ * batch * padded/32 * 36 bytes), ggq_cpu_mul_mat_q = the float sequences of the tensor-core bodies (HK/ggml/mmq.cuh:330-394,
+ * 913-974, 1274-1363) on exact integer dots; y: fp32 [batch, n_rows].  simd: 0 scalar, 2 at most AVX2, otherwise the widest
+ * of AVX-512 VNNI / AVX2 the host has — all paths bit-identical.  ggq_cpu_mmq_simd_name(): "avx512-vnni", "avx2", "scalar". */
+int ggq_cpu_quantize_q8_1_mmq(const float* x, void* q, int64_t batch, int64_t k, int type);
+int ggq_cpu_mul_mat_q(const void* w, const void* q, float* y, int type, int64_t batch, int64_t k, int64_t n_rows,
+                      int nthreads, int simd);
+const char* ggq_cpu_mmq_simd_name(void);
+
 /* ---- peer-mapped output slabs (multi-GPU, one process per GPU; no reference counterpart: the reference has no
  * multi-device code).  A rank exports the gather buffer it allocated as 64 opaque bytes + the byte offset of
  * the pointer inside its allocation; the other ranks import it and may then pass the mapped pointer as the `y` / `dst` of

@@ -83,3 +83,63 @@ def test_errors(ops):
     with pytest.raises(RuntimeError):
         ops.ggml_dequantize(w.T, int(GGMLType.Q4_0), 4, 64)    # non-contiguous
     assert ops.ggml_dequantize(w[:0], int(GGMLType.Q4_0), 0, 64).shape == (0, 64)
+
+
+# ---- host twin of the quantised GEMM (ggq_cpu_quantize_q8_1_mmq + ggq_cpu_mul_mat_q): bench.py's threaded CPU column ----
+MMQ_CPU_TYPES = [GGMLType.Q4_K, GGMLType.Q4_0, GGMLType.Q8_0]
+
+
+def _cpu_mmq(w, x, t, n_rows, threads, simd):
+    L = ggqlib.cpu()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    batch, k = x.shape
+    q = np.zeros(((k - k % 512 + 512) // 128) * batch * 144, np.uint8)
+    assert L.ggq_cpu_quantize_q8_1_mmq(p(x), p(q), batch, k, int(t)) == 0
+    y = np.full((batch, n_rows), np.nan, np.float32)
+    assert L.ggq_cpu_mul_mat_q(p(w), p(q), p(y), int(t), batch, k, n_rows, threads, simd) == 0
+    return q, y
+
+
+@pytest.mark.parametrize("quant_type", MMQ_CPU_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("shape", [(1, 256, 3), (5, 512, 17), (8, 1280, 64), (33, 2048, 40)], ids=str)
+def test_cpu_mmq_bit_exact_vs_oracle(quant_type, shape):
+    """every SIMD path and the threaded split give the oracle's bits: integer dots are exact, the float sequence is the oracle's"""
+    from oracle import oracle as O
+    batch, k, n_rows = shape
+    w = synth.random_weight(quant_type, n_rows, k, seed=k + batch)
+    x = np.random.default_rng(batch).standard_normal((batch, k)).astype(np.float32)
+    x[0, :32] = 0.0                                              # an all-zero group (d = 0)
+    want_q = O.quantize_q8_1_mmq(x, quant_type)
+    want_y, _ = O.mul_mat_q(w, x, quant_type, n_rows)
+    for threads, simd in ((1, 0), (1, 1), (1, 2), (3, 1)):
+        q, y = _cpu_mmq(w, x, quant_type, n_rows, threads, simd)
+        assert np.array_equal(q, want_q), (threads, simd)
+        assert np.array_equal(y.view(np.uint32), want_y.view(np.uint32)), (threads, simd)
+    assert ggqlib.cpu().ggq_cpu_mmq_simd_name() in (b"avx512-vnni", b"avx2", b"scalar")
+
+
+def test_cpu_mmq_extreme_bytes():
+    """Q8_0 weights of -128 / 127 against activations of +-127: the unsigned x signed byte-dot must not saturate"""
+    from oracle import oracle as O
+    k, n_rows = 512, 4
+    w = synth.random_weight(GGMLType.Q8_0, n_rows, k, seed=0).reshape(n_rows, k // 32, 34).copy()
+    w[0, :, 2:] = 0x80
+    w[1, :, 2:] = 0x7F
+    w[2, :, 2::2] = 0x80
+    w = w.reshape(n_rows, -1)
+    x = np.ones((3, k), np.float32)
+    x[1] = -1.0
+    x[2, ::3] = -1.0
+    want, _ = O.mul_mat_q(w, x, GGMLType.Q8_0, n_rows)
+    for simd in (0, 1, 2):
+        _, y = _cpu_mmq(w, x, GGMLType.Q8_0, n_rows, 1, simd)
+        assert np.array_equal(y.view(np.uint32), want.view(np.uint32)), simd
+
+
+def test_cpu_mmq_errors():
+    L = ggqlib.cpu()
+    assert L.ggq_cpu_mul_mat_q(None, None, None, int(GGMLType.Q6_K), 1, 256, 1, 1, 1) == -1    # only the three headline formats
+    assert L.ggq_cpu_mul_mat_q(None, None, None, int(GGMLType.Q4_K), 1, 100, 1, 1, 1) == -2
+    assert L.ggq_cpu_mul_mat_q(None, None, None, int(GGMLType.Q4_K), 1, 256, 1, 1, 1) == -4
+    assert L.ggq_cpu_mul_mat_q(None, None, None, int(GGMLType.Q4_K), 0, 256, 1, 1, 1) == 0
+    assert L.ggq_cpu_quantize_q8_1_mmq(None, None, 1, 256, 9) == -1
