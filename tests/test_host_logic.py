@@ -92,3 +92,12 @@ def test_mmq_routing_table():
     assert L.ggq_mmq_route(20, 8, 4096, 64) == NONE   # IQ4_NL: no GEMM
     # 32-bit offsets: a scratch of 2 GiB or more stays off the 16-token-tile kernel
     assert L.ggq_mmq_route(Q4_K, 32, 1 << 26, 64) != T16 and L.ggq_mmq_route(Q4_K, 32, 1 << 21, 64) == T16
+
+
+def test_shipped_code_objects_keep_the_mfma_wait_states():
+    """scripts/audit_kernels.py over lib/libggq_hip.so: every v_mfma_i32_32x32x32_i8 keeps the wait states the hardware was
+    measured to need and not to interlock (scripts/ubench_mfma_hazard.hip, profiles/r03_ubench_mfma_hazard.txt)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "audit_kernels.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "MFMA wait-state violations 0" in r.stdout
