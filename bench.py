@@ -44,6 +44,10 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (same guide: 2x the ~2.5 PF bf16 rate)
+# What a block-quantised GEMM can reach of that peak on this SIMD: every 32x32x32 int8 tile (13.4 ns of matrix pipe at the nominal
+# peak, 15.8 ns measured) is followed by two exact FMAs per (row, token, 32-group) triple = 16 v_pk_fma_f32 = 30.5 ns, and the SIMD
+# does not overlap the two (scripts/ubench_mfma.hip, ubench_overlap.hip): 13.4 / (15.8 + 30.5) = 0.29.
+SCALED_INT8_CEILING = 0.29
 Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 = 12, 13, 14, 2, 8
 NAMES = {Q4_K: "Q4_K", Q4_0: "Q4_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q6_K: "Q6_K"}
 K_DIM, N_DIM, BATCH = 4096, 11008, 128
@@ -119,6 +123,7 @@ def rates(stats, nbytes, ops=None):
     if ops:
         r["TOP/s"] = round(ops / (us * 1e-6) / 1e12, 2)
         r["pct_int8_mfma_peak"] = round(100 * ops / (us * 1e-6) / 1e12 / INT8_PEAK_TOPS, 2)
+        r["pct_of_per_group_scaling_ceiling"] = round(r["pct_int8_mfma_peak"] / SCALED_INT8_CEILING, 2)   # of the 29 % such a GEMM can reach
     return r
 
 
@@ -572,6 +577,8 @@ def main():
                            "limiter": "the SIMD's own arithmetic, not HBM: 2 exact FMAs per (row, token, 32-group) triple + the int8 MFMAs, which this SIMD does not overlap with packed FMAs (scripts/ubench_overlap.hip); DESIGN.md §5.4",
                            "int8_mfma_TOPs": round(ops / (st_cold["us"] * 1e-6) / 1e12, 2),
                            "frac_int8_mfma_peak": round(ops / (st_cold["us"] * 1e-6) / 1e12 / INT8_PEAK_TOPS, 4),
+                           "int8_ceiling_with_per_group_scales": SCALED_INT8_CEILING,
+                           "frac_of_that_ceiling": round(ops / (st_cold["us"] * 1e-6) / 1e12 / INT8_PEAK_TOPS / SCALED_INT8_CEILING, 4),
                            "note": "duration = HIP-event time of 208 back-to-back launches / 208 on the launch stream, median of 9 repeats"}
         if not args.no_extra:
             out["extra"] = secondary_configs(L, dev, w, w_ring, x, scratch, args)

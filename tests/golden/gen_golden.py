@@ -76,5 +76,27 @@ def main():
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
+def iq_pins():
+    """oracle_pins_iq.npz: the oracle's outputs for the nine IQ formats (dequantise fp16 bits, MMVQ results) — frozen so that
+    a later edit of the oracle or of the codebook tables cannot move both sides of the GPU parity tests together.
+    `python tests/golden/gen_golden.py iq` (needs no reference build)."""
+    from ggq.formats import IQ_TYPES
+    O.build()
+    pins = {}
+    x = np.random.default_rng(11).standard_normal((1, 512)).astype(np.float32)
+    for t in IQ_TYPES:
+        qk, bs = BLOCK[t]
+        blocks = np.concatenate([synth.random_blocks(t, 16, seed=400 + int(t)), synth.edge_blocks(t)[:24]])
+        f16 = O.dequantize_f16(blocks, t, blocks.shape[0] * qk)
+        assert np.array_equal(f16.astype(np.float32), N.dequantize_f16(blocks, t).reshape(-1).astype(np.float32), equal_nan=True), t
+        w = synth.random_weight(t, 12, 512, seed=500 + int(t))
+        yv, _ = O.mul_mat_vec_q(w, x, t, 12)
+        pins[f"{t.name}_blocks"], pins[f"{t.name}_f16_bits"] = blocks, f16.view(np.uint16)
+        pins[f"{t.name}_mm_w"], pins[f"{t.name}_mmvq_y"] = w, yv
+    pins["mm_x"] = x
+    np.savez_compressed(os.path.join(HERE, "oracle_pins_iq.npz"), **pins)
+    print("oracle_pins_iq.npz", os.path.getsize(os.path.join(HERE, "oracle_pins_iq.npz")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    iq_pins() if sys.argv[1:] == ["iq"] else main()

@@ -103,6 +103,18 @@ def test_oracle_pins(oracle, t):
     assert np.array_equal(yv, g[f"{t.name}_mmvq_y"]) and np.array_equal(ym, g[f"{t.name}_mmq_y"])
 
 
+@pytest.mark.parametrize("t", IQ_TYPES, ids=lambda t: t.name)
+def test_oracle_pins_iq(oracle, t):
+    g = np.load(os.path.join(GOLD, "oracle_pins_iq.npz"))
+    blocks = g[f"{t.name}_blocks"]
+    f16 = oracle.dequantize_f16(blocks, t, blocks.shape[0] * BLOCK[t][0])
+    a, b = f16.view(np.uint16), g[f"{t.name}_f16_bits"]
+    nan = np.isnan(f16)
+    assert np.array_equal(a[~nan], b[~nan]) and np.array_equal(nan, np.isnan(b.view(np.float16)))
+    yv, _ = oracle.mul_mat_vec_q(g[f"{t.name}_mm_w"], g["mm_x"], t, 12)
+    assert np.array_equal(yv, g[f"{t.name}_mmvq_y"])
+
+
 def test_oracle_quantizer_pins_and_numpy(oracle):
     g = np.load(os.path.join(GOLD, "oracle_pins.npz"))
     x = g["q8_x"]
