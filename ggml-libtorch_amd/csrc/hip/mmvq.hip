@@ -25,6 +25,9 @@
 #ifndef GGQ_MMVQ_UNROLL
 #define GGQ_MMVQ_UNROLL 1
 #endif
+#ifndef GGQ_MMVQ_KSPLIT
+#define GGQ_MMVQ_KSPLIT 1   // 0: ablation build without the K-split instantiation (scripts/build_variant.sh)
+#endif
 #ifndef GGQ_MMVQ_ROWS
 #define GGQ_MMVQ_ROWS 3   // rows in flight per wave in the fused kernel
 #endif
@@ -465,7 +468,7 @@ static inline size_t mmvq_lds_bytes(int64_t k) { return (size_t)k + (size_t)(k /
 // FUSED: q8 is the activation row itself (dtype DT); every workgroup quantises it into LDS with the
 // arithmetic of quantize.hip (bit-identical d, q, sum) while its first weight bytes are in flight —
 // one launch instead of two (the second launch cost 2.3 of 8.8 us at the headline shape).
-template <int T, int DT, int ROWS, bool FUSED>
+template <int T, int DT, int ROWS, bool FUSED, bool KSPLIT>
 __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t* __restrict__ w,
                                                    const uint8_t* __restrict__ q8,
                                                    void* __restrict__ y, int k, int n_rows,
@@ -514,7 +517,9 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
       for (int r = 0; r < ROWS; ++r)
 #pragma unroll
         for (int sp = 0; sp < PS; ++sp)   // clamped, never predicated: rows / units past the end repeat valid bytes
-          pre[r][sp] = UnitDot<T>::load(w + (int64_t)min(rb + r, n_rows - 1) * row_bytes, min((int)(threadIdx.x & 63) + 64 * sp, units0 - 1));
+          pre[r][sp] = KSPLIT   // K-split launch (see the row loop): ROWS K-slices of the wave's one row
+                           ? UnitDot<T>::load(w + (int64_t)min(rb, n_rows - 1) * row_bytes, min((int)(threadIdx.x & 63) + 64 * (sp * ROWS + r), units0 - 1))
+                           : UnitDot<T>::load(w + (int64_t)min(rb + r, n_rows - 1) * row_bytes, min((int)(threadIdx.x & 63) + 64 * sp, units0 - 1));
     }
     auto dppf = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false)); };
     auto dppi = [](int x, auto ctrl) { return __builtin_amdgcn_update_dpp(0, x, decltype(ctrl)::value, 0xF, 0xF, false); };
@@ -601,7 +606,7 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
     for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
     int u_first = lane;
     if constexpr (PRE) {
-      if (r0 == row_begin) {   // wave-uniform: the prefetched steps of the first row group
+      if (!KSPLIT && r0 == row_begin) {   // wave-uniform: the prefetched steps of the first row group
 #pragma unroll
         for (int sp = 0; sp < PS; ++sp) {
           const int u = lane + 64 * sp;
@@ -612,6 +617,38 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
           }
         }
         u_first = lane + 64 * PS;
+      }
+    }
+    if constexpr (FUSED && KSPLIT) {
+      // Long rows, few of them (n_rows <= the launch's wave count, e.g. the 4096 x 11008 down projection: one row per wave):
+      // the ROWS in-flight slots become K-slices of the wave's one row, so that a lane still has ROWS independent loads
+      // outstanding.  A separate instantiation chosen per launch, not per row group: every row of the matrix is summed in the same
+      // order, and the rows-in-flight form keeps its register budget (a runtime flag cost Q4_K / Q6_K 53 spilled registers).
+      {
+        if constexpr (PRE) {
+#pragma unroll
+          for (int sp = 0; sp < PS; ++sp)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+              const int u = lane + 64 * (sp * ROWS + r);   // clamped + selected, never predicated: no divergent control flow
+              const float d = UnitDot<T>::dot(pre[r][sp], min(u, units - 1), A);
+              acc[r] += u < units ? d : 0.0f;
+            }
+          u_first = lane + 64 * ROWS * PS;
+        }
+        for (int u = u_first; u < units; u += 64 * ROWS) {
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const float d = UnitDot<T>::run(w + (int64_t)r0 * row_bytes, min(u + 64 * r, units - 1), A);
+            acc[r] += u + 64 * r < units ? d : 0.0f;
+          }
+        }
+        float tot = acc[0];
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) tot += acc[r];
+        tot = wave_sum(tot);
+        if (lane == 0) Elem<DT>::st(y, r0, tot);
+        continue;
       }
     }
 #pragma unroll GGQ_MMVQ_UNROLL
@@ -653,7 +690,8 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
     grid = (n + 15) / 16;   // at least one row per wave before a CU is left without a workgroup
     grid = grid > 256 ? 256 : grid;
   }
-  auto kern = mmvq_kernel<T, DT, ROWS, FUSED>;
+  const bool ksplit = GGQ_MMVQ_KSPLIT && FUSED && n <= grid * 16;   // at most one row per wave: K-split over the in-flight slots (see the kernel)
+  auto kern = ksplit ? mmvq_kernel<T, DT, ROWS, FUSED, FUSED> : mmvq_kernel<T, DT, ROWS, FUSED, false>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GGQ_ERR_LAUNCH;

@@ -140,6 +140,36 @@ def test_mmvq_vs_oracle(oracle, dtype, t, k, n_rows):
     util.assert_fp_accumulate(y, ref.reshape(1, -1), yabs.reshape(1, -1), dtype, f"mmvq {t.name}")
 
 
+@pytest.mark.parametrize("t", WEIGHT_TYPES + IQ_TYPES, ids=lambda t: t.name)
+def test_mmvq_more_rows_than_waves(oracle, t):
+    """the fused GEMV has two row loops: K-split over the in-flight slots when the launch has at most one row per wave (every
+    small case above), rows in flight otherwise — this is the otherwise, with a ragged last row group per wave"""
+    k, n_rows = 512, 2 * 4096 + 5
+    w = synth.random_weight(t, n_rows, k, seed=9)
+    x = _x((1, k), torch.float16, seed=8)
+    y = util.gpu_mmvq(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_vec_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref.reshape(1, -1), yabs.reshape(1, -1), torch.float16, f"mmvq rows>waves {t.name}")
+
+
+@pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q4_K, GGMLType.Q6_K, GGMLType.IQ3_S], ids=lambda t: t.name)
+def test_mmvq_long_rows_few_of_them(oracle, t):
+    """the down-projection shape (4096 x 11008: one row per wave, K-split): oracle on a sample of rows, bit-reproducible,
+    and a row's result does not depend on where the row sits (the split is decided per launch, not per row group)"""
+    n_rows, k = 4096, 11008 if BLOCK[t][0] == 32 else 11008 // 256 * 256
+    w = synth.random_weight(t, n_rows, k, seed=41)
+    x = _x((1, k), torch.float32, seed=42)
+    y = util.gpu_mmvq(w, x, t, n_rows)
+    rows = np.r_[0:40, 2000:2040, n_rows - 40:n_rows]
+    ref, yabs = oracle.mul_mat_vec_q(w[rows], x.cpu().numpy(), t, len(rows))
+    util.assert_fp_accumulate(y[:, torch.from_numpy(rows).cuda()], ref.reshape(1, -1), yabs.reshape(1, -1), torch.float32, f"mmvq long {t.name}")
+    assert torch.equal(util.gpu_mmvq(w, x, t, n_rows), y), "not reproducible run to run"
+    perm = np.random.default_rng(5).permutation(n_rows)
+    assert torch.equal(util.gpu_mmvq(np.ascontiguousarray(w[perm]), x, t, n_rows), y[:, torch.from_numpy(perm).cuda()]), "y(P W) != y(W) P"
+    sub = 1500   # fewer rows than waves: some waves idle, same per-row arithmetic
+    assert torch.equal(util.gpu_mmvq(np.ascontiguousarray(w[:sub]), x, t, sub), y[:, :sub])
+
+
 @pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q5_1, GGMLType.Q8_0], ids=lambda t: t.name)
 def test_mmvq_k_not_multiple_of_256(oracle, t):
     k, n_rows = 32 * 37, 19
