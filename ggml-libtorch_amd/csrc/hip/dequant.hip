@@ -31,9 +31,10 @@
 // contiguous) with ALL loads of the thread issued first.  Streamed from HBM the one-chunk form is bound by latency x
 // resident waves (8192 waves x 1.3 KB per ~2.5 us round trip = 4 TB/s); three chunks in flight per thread give
 // Q4_K 48 -> 60 % of the roof cold (29.8 -> 23.9 us) at +-2 % warm.  Sweep 1/2/3/4/6/8 over all formats in
-// profiles/r02_dequant_chunks.txt: 3 or 4 is best everywhere except Q3_K, whose four 2-byte-aligned loads per chunk
-// bound it in the texture path either way.  The loads can only be hoisted because the decoders are branch-free.
-#define GGQ_DEQUANT_CH(T) ((T) == GGQ_TYPE_Q3_K ? 1 : 3)
+// profiles/r02_dequant_chunks.txt: 3 or 4 is best everywhere.  (Q3_K was the exception while its four loads per chunk were
+// 2-byte aligned and bound it in the texture path; with the aligned loads of its decoder below it is 44 -> 55.6 % of the roof
+// cold at three chunks, 53.4 % at one.)  The loads can only be hoisted because the decoders are branch-free.
+#define GGQ_DEQUANT_CH(T) 3
 #endif
 
 namespace ggq {
@@ -51,6 +52,17 @@ __device__ __forceinline__ h2 u8pair_to_h2(uint32_t p, int pair) {   // bytes 2Â
 __device__ __forceinline__ void st_h2(_Float16* y, int i, h2 v) { y[i] = v[0]; y[i + 1] = v[1]; }
 // bit k (k = 0..3) of x -> bit 0 of byte k (the four partial products do not overlap)
 __device__ __forceinline__ uint32_t bits4_to_bytes(uint32_t x) { return ((x & 0xF) * 0x00204081u) & 0x01010101u; }
+
+// An 8-byte field at a 2-byte aligned address p, read with ALIGNED loads: three dwords from p - (p & 2), funnelled into
+// place (v_alignbyte_b32).  The texture path charges a 2-byte-aligned dword load about three times an aligned one
+// (scripts/ubench_gload_align.hip).  Reads bytes [p - 2, p + 10) or [p, p + 12): only for fields with 4 valid bytes behind them
+// and 2 in front (inside a block, or in the block before).
+struct __attribute__((aligned(4))) u32x3 { uint32_t v[3]; };
+struct u32x2 { uint32_t v[2]; };
+__device__ __forceinline__ u32x2 ld8_aligned(const uint8_t* p, uint32_t sh) {   // sh = p & 2 (the block's: field offsets are multiples of 4)
+  const u32x3 a = *(const u32x3*)(p - sh);
+  return u32x2{{__builtin_amdgcn_alignbyte(a.v[1], a.v[0], sh), __builtin_amdgcn_alignbyte(a.v[2], a.v[1], sh)}};
+}
 
 // ---- per-format decode of the 8-element chunk `sub` of one block -----------
 template <int T> struct Decode;
@@ -150,20 +162,27 @@ template <> struct Decode<GGQ_TYPE_Q2_K> {
   }
 };
 template <> struct Decode<GGQ_TYPE_Q3_K> {
+  // 110-byte blocks: every field of an even block is 4-byte aligned and every field of an odd block is 2 mod 4.  The texture
+  // path charges a 2-byte-aligned dword load about three times an aligned one (scripts/ubench_gload_align.hip), which held
+  // this format at 38 - 44 % of the HBM roof cold with four such loads per chunk.  So: the two 8-byte fields are read with
+  // ld8_aligned (the surplus bytes are the block's own neighbours, or the last two bytes of the block before â€” block 0 of
+  // a 4-byte aligned tensor is even), the two scale bytes and d as naturally aligned byte / halfword loads.
   static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
     const int n = sub >> 4, j = (sub >> 2) & 3, l0 = 8 * (sub & 3);
     const _Float16 d_all = bits_h(ld_u16(b + off::Q3_K_D));
-    const u32x3_a2 s = ld_u32x3(b + off::Q3_K_SC);
-    const int us = q3k_scale(s.v[0], s.v[1], s.v[2], sub >> 1);
+    const int i = sub >> 1;   // 16-element group: low nibble (i / 8) of scale byte i % 8, bit pair (i / 4) of byte 8 + i % 4 (dequantize.cuh:140-143)
+    const uint32_t blo = b[off::Q3_K_SC + (i & 7)], bhi = b[off::Q3_K_SC + 8 + (i & 3)];
+    const int us = (int)(((blo >> (4 * (i >> 3))) & 0xF) | (((bhi >> (2 * (i >> 2))) & 3) << 4)) - 32;
     const _Float16 dl = d_all * i2h(us);  // dequantize.cuh:144-145 (us already minus 32)
-    const u32x2_a2 q = ld_u32x2(b + off::Q3_K_QS + 32 * n + l0);
-    const u32x2_a2 hm = ld_u32x2(b + off::Q3_K_HM + l0);
+    const uint32_t sh = (uint32_t)((uintptr_t)b & 2);
+    const u32x2 qq = ld8_aligned(b + off::Q3_K_QS + 32 * n + l0, sh), hh = ld8_aligned(b + off::Q3_K_HM + l0, sh);
+    const uint32_t q[2] = {qq.v[0], qq.v[1]}, hm[2] = {hh.v[0], hh.v[1]};
     const int hbit = 4 * n + j;
     const h2 dl2 = {dl, dl}, four = {(_Float16)4.0f, (_Float16)4.0f};
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       // bytes: q2 + 4Â·h in 0..7; (q2 - (h ? 0 : 4)) = that minus 4 â€” exact either way (dequantize.cuh:151)
-      const uint32_t v4 = ((q.v[w] >> (2 * j)) & 0x03030303u) + (((hm.v[w] >> hbit) & 0x01010101u) << 2);
+      const uint32_t v4 = ((q[w] >> (2 * j)) & 0x03030303u) + (((hm[w] >> hbit) & 0x01010101u) << 2);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) st_h2(y, 4 * w + 2 * pr, dl2 * (u8pair_to_h2(v4, pr) - four));
     }
@@ -214,8 +233,10 @@ template <> struct Decode<GGQ_TYPE_Q6_K> {
     const int ip = sub >> 4, j = (sub >> 2) & 3, l0 = 8 * (sub & 3);
     const _Float16 d = bits_h(ld_u16(b + off::Q6_K_D));
     const int sc = (int8_t)b[off::Q6_K_SC + (sub >> 1)];
-    const u32x2_a2 ql = ld_u32x2(b + off::Q6_K_QL + 64 * ip + 32 * (j & 1) + l0);
-    const u32x2_a2 qh = ld_u32x2(b + off::Q6_K_QH + 32 * ip + l0);
+    // 210-byte blocks: odd blocks are 2 mod 4 â€” aligned loads as for Q3_K
+    const uint32_t sh = (uint32_t)((uintptr_t)b & 2);
+    const u32x2 ql = ld8_aligned(b + off::Q6_K_QL + 64 * ip + 32 * (j & 1) + l0, sh);
+    const u32x2 qh = ld8_aligned(b + off::Q6_K_QH + 32 * ip + l0, sh);
     // i2h(scÂ·(q-32)) = one round-to-nearest of an exact integer product = the fp16 product of the exact halves
     const h2 d2 = {d, d}, sc2 = {i2h(sc), i2h(sc)}, off2 = {(_Float16)32.0f, (_Float16)32.0f}, zero2 = {(_Float16)0.0f, (_Float16)0.0f};
 #pragma unroll
