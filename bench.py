@@ -453,6 +453,7 @@ def main():
                     print(f"[bench] graph capture failed ({e}); timing eager launches", file=sys.stderr)
                     graph = None
                     torch.cuda.synchronize()
+            done = torch.cuda.Event()
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -461,6 +462,11 @@ def main():
             else:
                 for i in range(args.steps):
                     step(i, ring)
+            # poll before the blocking synchronize: a sleeping host thread is woken 10-30 us after the GPU is done, which at
+            # the driver's --steps 20 (0.6 ms of GPU work) is 2-5 % of the timed region; the synchronize still brackets it
+            done.record()
+            while not done.query():
+                pass
             torch.cuda.synchronize()
             barrier()
             return time.perf_counter() - t0, graph is not None

@@ -952,28 +952,35 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
         const uint32_t m4 = ((((w2 >> 4) & 0x0F0F0F0Fu) | ((w1 >> 2) & 0x30303030u)) & hm) | (w1 & 0x3F3F3F3Fu & ~hm);
         const float dmin = bits_h_f32((uint32_t)hd[0] >> 16);
         // -dmin·m_g = hi + lo exactly, both fp16 (RTZ for hi: any rounding leaves a representable remainder).  Only
-        // |dmin·m| beyond the fp16 range cannot be split: then the whole wave takes the 2^-8-scaled form below.
-        const bool big = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(dmin) <= 1024.0f)) != 0;
-        const float dm = big ? dmin * 0.00390625f : dmin;
-        v4i av;   // k order of the lane half: hi(g0) hi(g1) lo(g0) lo(g1) hi(g2) hi(g3) lo(g2) lo(g3), g = group - 4h
+        // |dmin·m| beyond the fp16 range cannot be split: such a ROW (lane) contributes nothing to the MFMA below and goes
+        // through the 2^-8-scaled pass of the cold branch instead, in which the other rows contribute nothing — so a row's
+        // result does not depend on which rows share its tile.
+        const bool lane_big = !(__builtin_fabsf(dmin) <= 1024.0f);
+        const bool big = __builtin_amdgcn_ballot_w64(lane_big) != 0;
+        auto split4 = [&](float dm) {   // k order of the lane half: hi(g0) hi(g1) lo(g0) lo(g1) hi(g2) hi(g3) lo(g2) lo(g3), g = group - 4h
+          v4i av;
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          const float p0 = -(dm * (float)((m4 >> (8 * j)) & 0xFF)), p1 = -(dm * (float)((m4 >> (8 * j + 8)) & 0xFF));
-          const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-          av[j] = (int)hb;
-          av[j + 1] = (int)__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0 - bits_h_f32(hb & 0xFFFF), p1 - bits_h_f32(hb >> 16)));
-        }
+          for (int j = 0; j < 4; j += 2) {
+            const float p0 = -(dm * (float)((m4 >> (8 * j)) & 0xFF)), p1 = -(dm * (float)((m4 >> (8 * j + 8)) & 0xFF));
+            const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+            av[j] = (int)hb;
+            av[j + 1] = (int)__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0 - bits_h_f32(hb & 0xFFFF), p1 - bits_h_f32(hb >> 16)));
+          }
+          return av;
+        };
+        const v4i av = split4(lane_big ? 0.0f : dmin);
 #pragma unroll
         for (int jj = 0; jj < TB; ++jj) {
           const v2u x = *(const v2u*)(s8l + (jj * 32 + r) * 4 + 2 * h);   // s8 of groups 4h .. 4h+3 of token r
           const v4i bv = {(int)x[0], (int)x[0], (int)x[1], (int)x[1]};   // s8(g0) s8(g1) twice, s8(g2) s8(g3) twice: matches av
           const h8 ah = __builtin_bit_cast(h8, av), bh = __builtin_bit_cast(h8, bv);
           acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[jj], 0, 0, 0);
-          if (__builtin_expect(big, 0)) {   // cold: the 2^-8-scaled operand was accumulated once, 255 more to go
+          if (__builtin_expect(big, 0)) {   // cold: the rows with |dmin| > 1024 at 2^-8 of their scale, times 256 (exact) afterwards
+            const v4i avs = split4(lane_big ? dmin * 0.00390625f : 0.0f);
             v16f z = {};
-            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, avs), bh, z, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[jj][i] = __builtin_fmaf(z[i], 255.0f, acc[jj][i]);
+            for (int i = 0; i < 16; ++i) acc[jj][i] = __builtin_fmaf(z[i], 256.0f, acc[jj][i]);
           }
         }
       }

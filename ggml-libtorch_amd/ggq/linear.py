@@ -75,6 +75,8 @@ def _matmul_epi(qa: "QuantizedActivations", w, quant_type, rows, epi, aux, out=N
     if w.device != qa.device or aux.device != qa.device or aux.dtype != qa.x_dtype or not aux.is_contiguous():
         raise ValueError("weights and the epilogue operand must be contiguous, of X's dtype, on X's device")
     y = out if out is not None else torch.empty((qa.batch, rows), dtype=qa.x_dtype, device=qa.device)
+    if out is not None and out.data_ptr() == aux.data_ptr():
+        raise ValueError("the epilogue operand must not alias the output (the kernel declares both __restrict__)")
     if epi == EPI_BIAS and aux.numel() != rows:
         raise ValueError("bias must have one element per output row")
     if epi == EPI_SILU_MUL and (aux.shape != y.shape or aux.stride(0) != y.stride(0)):

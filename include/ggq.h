@@ -154,7 +154,8 @@ int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int type, int 
  * Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q4_K, 33 for Q6_K, 65 for Q8_0) for every (type, k) ggq_mmq_tiled_supported() reports: all ten formats, k a whole
  * number of blocks, rows of at most 32 MiB; exported so a caller can quantise once for several weight
  * matrices (the reference quantises per call, HK/ggml/mmq.cu:208-230).
- * q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte aligned.  w must be 16-byte aligned. */
+ * q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte aligned.  w: 2-byte aligned as everywhere
+ * (GGQ_ERR_ALIGN otherwise). */
 int ggq_mmq_tiled_supported(int type, int64_t k);
 int ggq_quantize_q8_1_tiled(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
                             int type, void* stream);

@@ -241,6 +241,10 @@ def test_mmq_streamed_min_scale_range(oracle, t, batch):
     ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
     assert np.isfinite(ref).all()
     util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"streamed mmq min range {t.name} b={batch}")
+    # a row's result does not depend on which rows share its 32-row tile: the |dmin| > 1024 rows take the scaled pass alone
+    perm = np.random.default_rng(4).permutation(n_rows)
+    yp = util.gpu_mmq_pretiled(np.ascontiguousarray(w[perm]), x, t, n_rows)
+    assert torch.equal(yp, y[:, torch.from_numpy(perm).cuda()]), "Y(P W) != Y(W) P with mixed |dmin| ranges in one tile"
 
 
 def test_mmq_streamed_ldy_and_errors(oracle):
