@@ -255,8 +255,14 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
         v4i b_a, b_b, b_c, b_d;   // group 4q (low nibbles, lanes c < 2), 4q+1 (high, c < 2), 4q+2 (low, c >= 2), 4q+3 (high, c >= 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          b_a[i] = c < 2 ? b_lo[i] : 0; b_b[i] = c < 2 ? b_hi[i] : 0;
-          b_c[i] = c < 2 ? 0 : b_lo[i]; b_d[i] = c < 2 ? 0 : b_hi[i];
+          if constexpr (!F::has_qh) {   // the lane masks ARE the nibble masks (all ones or zero per lane): no selects
+            const uint32_t hi4 = raw[i] >> 4;
+            b_a[i] = (int)(raw[i] & m_lo); b_b[i] = (int)(hi4 & m_lo);
+            b_c[i] = (int)(raw[i] & m_hi); b_d[i] = (int)(hi4 & m_hi);
+          } else {
+            b_a[i] = c < 2 ? b_lo[i] : 0; b_b[i] = c < 2 ? b_hi[i] : 0;
+            b_c[i] = c < 2 ? 0 : b_lo[i]; b_d[i] = c < 2 ? 0 : b_hi[i];
+          }
         }
         float dw[4];
 #pragma unroll

@@ -101,3 +101,17 @@ def test_shipped_code_objects_keep_the_mfma_wait_states():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "audit_kernels.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "MFMA wait-state violations 0" in r.stdout
+
+
+def test_waitcnt_placement_of_the_headline_and_mid_batch_kernels():
+    """scripts/check_waitcnt.py (static, path-sensitive): every register a load / LDS read / scalar load returns into is waited
+    for before any later instruction touches it, loop-carried uses included — on the kernel the bench line is measured on and on
+    the Q4_K fp16 16-token-tile instances (the whole library takes 49 minutes: profiles/r03_waitcnt_check.txt)."""
+    import subprocess, sys
+    lib = os.path.join(ROOT, "ggml-libtorch_amd", "lib", "libggq_hip.so")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_waitcnt.py"), lib,
+                        "mmq_stream_kernelILi12ELi1ELi2ELi4ELi0E", "mmq_t16_kernelILi12ELi1E"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 unwaited register uses" in r.stdout and "kernels checked" in r.stdout
+    n = int(r.stdout.strip().split("\n")[-1].split(" kernels checked")[0])
+    assert n >= 5, r.stdout[-500:]
