@@ -100,7 +100,8 @@ extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
 // Host-only and exported so that the table can be tested without a GPU (tests/test_host_logic.py).
 extern "C" int ggq_mmq_t16_type_supported(int type) {
   switch (type) {
-    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: return 1;
+    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: case GGQ_TYPE_Q8_0:
+    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: case GGQ_TYPE_Q5_1: return 1;
     default: return 0;
   }
 }
@@ -108,6 +109,7 @@ extern "C" int ggq_mmq_t16_type_supported(int type) {
 extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
   // 256-element units; 32-bit byte offsets into the activation scratch
   if (!ggq_mmq_t16_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
+  if (ggq_block_elems(type) == 32 && batch > 16) return 0;   // the 32-element-block formats have no two-token-tile instance
   if ((uint64_t)ggq_mmq_scratch_bytes(batch, k) >= (1ull << 31)) return 0;
   if ((uint64_t)ggq_row_bytes(type, k) * 16 >= (1ull << 32)) return 0;   // 32-bit byte offsets inside a 16-row weight tile
   return 1;
@@ -123,8 +125,29 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   //   Q5_K 11008 x 4096   b8 15.2/18.7 -> 10.6/13.5   b16 18.0/20.2 -> 12.6/15.1   b32 15.8/20.2 -> 18.5/21.2
   // i.e. every shape from batch 2 (a tie at the one shape whose row count suits the dot4 kernel's 4096 waves) up to the
   // last batch one workgroup column covers without re-reading the weights: 32 tokens (two token tiles) for Q4_K, 16 for
-  // Q5_K whose two-tile instance sits at the register limit.
-  if (ggq_mmq_t16_supported(type, k, batch) && batch >= 2 && batch <= (type == GGQ_TYPE_Q4_K ? 32 : 16)) return GGQ_MMQ_ROUTE_T16;
+  // Q5_K and Q8_0 whose two-tile instances sit at / beyond the register limit.
+  // The 32-element-block formats (two request -> land -> compute rounds per wave for Q8_0, whose weights do not fit the chip's
+  // LDS in one go; one token tile only: batch <= 16), same sweep:
+  //   11008 x 4096   Q4_0 b2 9.4/12.3 -> 12.3/13.3   b4 10.8/13.1 -> 12.4/13.4   b5 13.6/15.9 -> 12.5/13.2   b8 14.0/16.2 -> 12.6/13.9   b16 17.2/20.9 -> 14.6/15.8
+  //                  Q4_1 b2 8.3/11.6 -> 12.6/13.6   b8 14.7/15.8 -> 12.9/13.7   b16 19.6/21.5 -> 16.2/17.4
+  //                  Q5_0 b8 15.1/16.8 -> 16.2/16.9   b16 18.4/23.3 -> 18.0/19.2     Q5_1 b8 15.8/17.1 -> 18.6/18.8   b16 19.7/23.1 -> 20.5/21.2
+  //                  Q8_0 b2 12.8/17.0 -> 13.4/15.1   b4 13.2/15.4 -> 13.4/15.2   b8 15.5/18.9 -> 14.2/15.8   b16 22.0/25.5 -> 14.6/16.7
+  //   3584 x 8192    Q4_0 b2 13.1/16.2 -> 9.6/10.0   b8 21.1/22.3 -> 9.7/10.1   b16 18.6/23.1 -> 11.5/11.9   Q5_0 b8 23.5/24.7 -> 11.9/12.3
+  //                  Q5_1 b8 23.7/24.5 -> 13.5/14.3   b16 20.1/21.5 -> 12.6/13.4   Q8_0 b2 10.2/11.4 -> 10.4/11.4   b8 24.2/26.8 -> 10.5/11.5
+  //   4096 x 11008   Q4_0 b2 17.2/21.1 -> 11.5/12.2   b8 28.9/29.9 -> 12.0/12.2   Q5_0 b8 32.7/32.9 -> 14.0/15.0   b16 22.7/26.2 -> 18.0/18.7
+  //                  Q5_1 b8 33.2/33.4 -> 12.9/13.9   b16 25.8/27.0 -> 20.6/21.6   Q8_0 b8 32.1/35.4 -> 13.6/15.7
+  // i.e. with fewer rows than the dot4 / streamed kernels need to fill the chip (< 8192) the 16-token tiles win from batch 2 for
+  // every format; with many rows they win from where the dot4 kernel stops scaling: batch 5 (Q4_0 Q4_1 Q8_0), 9 (Q5_0), never (Q5_1).
+  int64_t t16_from = 2, t16_to = 0;
+  switch (type) {
+    case GGQ_TYPE_Q4_K: t16_to = 32; break;
+    case GGQ_TYPE_Q5_K: t16_to = 16; break;
+    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q8_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
+    case GGQ_TYPE_Q5_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 9; break;
+    case GGQ_TYPE_Q5_1: t16_to = n_rows < 8192 ? 16 : 0; break;
+    default: break;
+  }
+  if (ggq_mmq_t16_supported(type, k, batch) && batch >= t16_from && batch <= t16_to) return GGQ_MMQ_ROUTE_T16;
   // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):
   // the dot4 kernel while it beats the streamed one with the weights coming from HBM, the barrier-coupled LDS-tile
   // kernel for the mid batches of the two formats whose streamed instance is bound by its weight copy, streamed beyond.

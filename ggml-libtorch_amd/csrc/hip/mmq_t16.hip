@@ -66,10 +66,22 @@ __device__ __forceinline__ float t16_epilogue(float v, int epi, const void* aux,
 }
 
 template <int T> struct T16Fmt {
-  static_assert(T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K, "format");
-  static constexpr int UB = 256 / Fmt<T>::QK * Fmt<T>::BS;   // bytes of one 256-element unit of a weight row
-  static constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : off::Q5_K_QS;
+  static_assert(T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K || T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 ||
+                T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1, "format");
+  static constexpr bool legacy = Fmt<T>::QK == 32;           // 32-element blocks {fp16 d [, fp16 m] [, u32 qh], qs}, no super-block header
+  static constexpr int UB = 256 / Fmt<T>::QK * Fmt<T>::BS;   // bytes of one 256-element unit of a weight row — a multiple of 16 for
+                                                             // every format here (eight 18 / 20 / 22 / 24 / 34-byte blocks: 144 .. 272)
+  static constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : T == GGQ_TYPE_Q5_K ? off::Q5_K_QS : 2;
   static constexpr bool has_qh = T == GGQ_TYPE_Q5_K;
+  // 32-element blocks
+  static constexpr int BS = Fmt<T>::BS;
+  static constexpr bool nib = legacy && T != GGQ_TYPE_Q8_0;                       // 4- / 5-bit values, 8 raw bytes per lane
+  static constexpr bool blk_qh = T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1;        // fifth bits: u32 behind the scale(s)
+  static constexpr bool blk_m = T == GGQ_TYPE_Q4_1 || T == GGQ_TYPE_Q5_1;         // half2(d, m), fp16 products (mmq.cuh:527-529)
+  static constexpr int BQH = blk_m ? 4 : 2;                                        // offset of qh
+  static constexpr int BQS = (blk_m ? 4 : 2) + (blk_qh ? 4 : 0);                   // offset of qs
+  static constexpr int sub = T == GGQ_TYPE_Q4_0 ? 8 : T == GGQ_TYPE_Q5_0 ? 16 : 0; // value = raw - sub (exact integer contraction)
+  static constexpr bool d8_half = T == GGQ_TYPE_Q4_0 || blk_m;                     // need_sum formats: the table holds half2(d8, s8)
 };
 
 // wave-private LDS (bytes): W [16 rows][MAXU units] raw bytes | TAB scale tables
@@ -175,6 +187,114 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
 #pragma unroll
   for (int jj = 0; jj < NTT; ++jj) accm[jj] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
   auto compute_unit = [&](int s, const Frags& Fr) {
+    if constexpr (F::legacy) {
+      // ---- 32-element blocks: the unit is eight blocks of row j.  Lane (row j, chunk c) of MFMA m of half q works on block
+      //      4 q + 2 m + (c >> 1), h = c & 1:
+      //        Q8_0   qs[16 h .. + 15] (a 2-byte aligned ds_read_b128): K order = element order;
+      //        nibble formats   qs[8 h .. + 7] (ds_read_b64): low nibbles = elements 8 h .., high nibbles = 16 + 8 h ..
+      //                         (+ the fifth bits of qh), which is the order the activation fragments are written in
+      //                         (quantize.hip, GGQ_T16_RUN8).
+      //      One MFMA covers two blocks (chunks 0-1 | 2-3), which M8 separates by its doubled token rows and the 16-token
+      //      form by zeroing the other block's lanes.  Factors as in the reference's tensor-core bodies: Q4_0 / Q5_0 / Q8_0
+      //      d d8 C with the offset subtracted from the weights (mmq.cuh:359, 561, 971), Q4_1 / Q5_1 fp16(d d8) C + fp16(m s8)
+      //      (:527-529). ----
+      typedef unsigned v4u_a2 __attribute__((ext_vector_type(4), aligned(2)));
+      typedef unsigned v2u_a2 __attribute__((ext_vector_type(2), aligned(2)));
+      struct __attribute__((packed, aligned(2))) u32_a2 { uint32_t v; };
+      const uint8_t* blk = wl + L::W + j * SB + s * UB;
+      const v4i zero = {0, 0, 0, 0};
+      auto sub_bytes = [](uint32_t x) {   // per byte x - sub as int8 (x <= 31): no borrow leaves a byte whose top bit is set
+        if constexpr (F::sub == 0) return x;
+        else return ((x | 0x80808080u) - 0x01010101u * (uint32_t)F::sub) ^ 0x80808080u;
+      };
+      auto operand = [&](int bi) {   // the lane's 16 K-values of block bi
+        const uint8_t* bp = blk + bi * F::BS;
+        if constexpr (!F::nib) {
+          const v4u_a2 t = *(const v4u_a2*)(bp + F::BQS + 16 * (c & 1));
+          return v4i{(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
+        } else {
+          const v2u_a2 x = *(const v2u_a2*)(bp + F::BQS + 8 * (c & 1));
+          uint32_t v[4] = {x[0] & 0x0F0F0F0Fu, x[1] & 0x0F0F0F0Fu, (x[0] >> 4) & 0x0F0F0F0Fu, (x[1] >> 4) & 0x0F0F0F0Fu};
+          if constexpr (F::blk_qh) {   // bit e of qh = fifth bit of element e: elements 8 h .. (byte h), 16 + 8 h .. (byte 2 + h)
+            const uint32_t qh = ((const u32_a2*)(bp + F::BQH))->v >> (8 * (c & 1));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t nb = (qh >> (16 * (i >> 1) + 4 * (i & 1))) & 0xF;
+              v[i] |= ((nb * 0x00204081u) & 0x01010101u) << 4;   // bit k -> bit 0 of byte k
+            }
+          }
+          return v4i{(int)sub_bytes(v[0]), (int)sub_bytes(v[1]), (int)sub_bytes(v[2]), (int)sub_bytes(v[3])};
+        }
+      };
+      // acc += the block's term for the token whose scale word is `tw` (fp32 d8 | half2(d8, s8)), C the integer dot,
+      // `bw` the block's scale word (fp16 d, or half2(d, m) read as one dword)
+      auto apply = [&](float a, int C, uint32_t tw, uint32_t bw) -> float {
+        if constexpr (F::blk_m) {
+          const h2 pr = __builtin_bit_cast(h2, bw) * __builtin_bit_cast(h2, tw);   // (d d8, m s8), each rounded to fp16
+          float fr;
+          asm("v_fma_mix_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(fr) : "v"(__builtin_bit_cast(uint32_t, pr)), "v"((float)C));
+          return a + fr;
+        } else if constexpr (F::d8_half) {
+          float t;
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t) : "v"((float)C), "v"(tw));
+          return __builtin_fmaf(t, bits_h_f32(bw & 0xFFFF), a);
+        } else {
+          return __builtin_fmaf((float)C * as_f32((int)tw), bits_h_f32(bw & 0xFFFF), a);
+        }
+      };
+      auto scale_word = [&](int bi) -> uint32_t {
+        if constexpr (F::blk_m) return ((const u32_a2*)(blk + bi * F::BS))->v;
+        else return *(const uint16_t*)(blk + bi * F::BS);
+      };
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        v4i b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) b[m] = operand(4 * q + 2 * m + (c >> 1));
+        if constexpr (M8) {
+          const uint8_t* tq = wl + L::TAB + s * 256 + q * 128;   // [token quad][group][token]
+          const v4u_t d0 = *(const v4u_t*)(tq + (c & 1) * 64 + sel * 16);         // block 4 q + sel, tokens 4 (c & 1) .. + 3
+          const v4u_t d1 = *(const v4u_t*)(tq + (c & 1) * 64 + (2 + sel) * 16);   // block 4 q + 2 + sel
+          const uint32_t bw0 = scale_word(4 * q + sel), bw1 = scale_word(4 * q + 2 + sel);
+          const v4i C0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][0][0], b[0], zero, 0, 0, 0);
+          const v4i C1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][0][1], b[1], zero, 0, 0, 0);
+          const uint32_t t0[4] = {d0[0], d0[1], d0[2], d0[3]}, t1[4] = {d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[0][r] = apply(acc[0][r], C0[r], t0[r], bw0);
+            acc[0][r] = apply(acc[0][r], C1[r], t1[r], bw1);
+          }
+        } else {
+          v4i bm[4];   // block 4 q + g: chunks 0-1 of MFMA g >> 1 for even g, chunks 2-3 for odd g
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bm[0][i] = c < 2 ? b[0][i] : 0; bm[1][i] = c < 2 ? 0 : b[0][i];
+            bm[2][i] = c < 2 ? b[1][i] : 0; bm[3][i] = c < 2 ? 0 : b[1][i];
+          }
+          uint32_t bw[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bw[g] = scale_word(4 * q + g);
+#pragma unroll
+          for (int jj = 0; jj < NTT; ++jj) {
+            const uint8_t* tq = wl + L::TAB + (jj * ((MAXU + 1) / 2) * 2 + s) * 512 + q * 256;
+            uint32_t tw[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const v4u_t t = *(const v4u_t*)(tq + c * 64 + g * 16);   // tokens 4 c .. 4 c + 3, block 4 q + g
+              tw[g][0] = t[0]; tw[g][1] = t[1]; tw[g][2] = t[2]; tw[g][3] = t[3];
+            }
+            v4i C[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) C[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[q][jj][g >> 1], bm[g], zero, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[jj][r] = apply(acc[jj][r], C[g][r], tw[g][r], bw[g]);
+          }
+        }
+      }
+      return;
+    } else {
     const uint8_t* blk = wl + L::W + j * SB + s * UB;   // row j's block of this unit
     const v4u_t hd = *(const v4u_t*)blk;   // {d | dmin << 16, scales[0..3], scales[4..7], scales[8..11]}
     v4u_t qh = {0, 0, 0, 0};
@@ -287,6 +407,7 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
           }
         }
       }
+    }
     }
   };
 
@@ -401,13 +522,31 @@ static int launch_t16(const void* w, const void* q8, void* y, int64_t batch, int
                                                    // two-unit M8 instance for 6 waves per SIMD spills 12 registers: 17.6 instead of 7.0 us)
   const int64_t n_units = k / 256;
   const int64_t n_wg = ((n + 15) / 16) * (M8 ? 1 : ((batch + 15) / 16 + NTT - 1) / NTT);
-  auto resident = [&](int64_t maxu) {
-    const int64_t ks = (n_units + maxu - 1) / maxu;
-    return ks <= MAXKS && n_wg <= 256 * (WAVES_PER_CU / ks);
+  // waves of one CU by LDS: the wave-private image of MAXU units + scale tables (the reduction scratch aliases it)
+  auto lds_waves = [&](int maxu) -> int64_t {
+    const int64_t w2 = T16Lds<T, M8, NTT, 2>::WAVE, w3 = T16Lds<T, M8, NTT, 3>::WAVE, w4 = T16Lds<T, M8, NTT, 4>::WAVE;
+    const int64_t wave = maxu == 2 ? w2 : maxu == 3 ? w3 : w4, red = (int64_t)NTT * 4 * 64 * 4;
+    return (160 * 1024) / (wave > red ? wave : red);
   };
-  if (resident(2)) return launch_t16_u<T, DT, M8, NTT, 2>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 1) / 2);
-  if (resident(3)) return launch_t16_u<T, DT, M8, NTT, 3>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 2) / 3);
-  return launch_t16_u<T, DT, M8, NTT, 4>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 3) / 4);
+  // every workgroup resident at once with `ups` units per wave, `maxu` of them in LDS at a time (ups > maxu: several
+  // request -> land -> compute rounds per wave — the formats whose weights do not fit the LDS of the chip in one go)
+  auto resident = [&](int64_t ups, int maxu) {
+    const int64_t ks = (n_units + ups - 1) / ups;
+    const int64_t wpc = WAVES_PER_CU < lds_waves(maxu) ? WAVES_PER_CU : lds_waves(maxu);
+    if (ups > maxu && (maxu & 1)) return false;   // several rounds: the two fragment buffers alternate by unit parity across rounds
+    return ks <= MAXKS && ks <= wpc && n_wg <= 256 * (wpc / ks);
+  };
+  for (int64_t ups = 2; ups <= 8; ++ups)
+    for (int maxu = ups < 4 ? (int)ups : 4; maxu >= 2; --maxu)
+      if (resident(ups, maxu)) {
+        const int64_t ks = (n_units + ups - 1) / ups;
+        if (maxu == 2) return launch_t16_u<T, DT, M8, NTT, 2>(w, q8, y, batch, k, n, ldy, s, ep, ks);
+        if (maxu == 3) return launch_t16_u<T, DT, M8, NTT, 3>(w, q8, y, batch, k, n, ldy, s, ep, ks);
+        return launch_t16_u<T, DT, M8, NTT, 4>(w, q8, y, batch, k, n, ldy, s, ep, ks);
+      }
+  // not resident in one go whatever the slicing (very many rows): four-unit slices, as many waves as fit
+  if (lds_waves(4) >= 4) return launch_t16_u<T, DT, M8, NTT, 4>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 3) / 4);
+  return launch_t16_u<T, DT, M8, NTT, 2>(w, q8, y, batch, k, n, ldy, s, ep, (n_units + 3) / 4);
 }
 
 template <int T, int DT>
@@ -415,7 +554,10 @@ static int launch_t16_dt(const void* w, const void* q8, void* y, int64_t batch, 
                          Epi16 ep) {
   if (batch <= 8) return launch_t16<T, DT, true, 1>(w, q8, y, batch, k, n, ldy, s, ep);   // (the scratch layout follows the batch too: quantize.hip)
   if (batch <= 16) return launch_t16<T, DT, false, 1>(w, q8, y, batch, k, n, ldy, s, ep);
-  return launch_t16<T, DT, false, 2>(w, q8, y, batch, k, n, ldy, s, ep);
+  // two token tiles per wave: the K-quants only (the 32-element-block instances spill 70 - 90 registers; ggq_mmq_t16_supported
+  // keeps their batches at 16)
+  if constexpr (T16Fmt<T>::legacy) return GGQ_ERR_SHAPE;
+  else return launch_t16<T, DT, false, 2>(w, q8, y, batch, k, n, ldy, s, ep);
 }
 
 template <int T>
@@ -449,6 +591,11 @@ extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type
   switch (type) {
     case GGQ_TYPE_Q4_K: return launch_t16_t<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     case GGQ_TYPE_Q5_K: return launch_t16_t<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q8_0: return launch_t16_t<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q4_0: return launch_t16_t<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q4_1: return launch_t16_t<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q5_0: return launch_t16_t<GGQ_TYPE_Q5_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q5_1: return launch_t16_t<GGQ_TYPE_Q5_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     default: return GGQ_ERR_TYPE;
   }
 }

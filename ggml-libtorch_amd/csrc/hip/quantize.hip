@@ -35,6 +35,22 @@ __device__ __forceinline__ void load4(const void* x, int64_t base, int64_t ix, i
 //           nibble v (t16_inverse_perm below).
 // LAYOUT 4: LAYOUT 3 for at most 8 tokens, half the bytes: 2304-byte tiles { int8 frag[4][4 K-chunks][8 tokens][16];
 //           ds[2 halves][2 token quads][4 groups][4 tokens] } (what ggq_quantize_q8_1_t16 writes for batch <= 8).
+// element e256 of a 256-element unit -> (16-byte slot 4 f + c of the tile, byte inside the slot).  `inv` = the format's nibble
+// table of 16-element runs, or GGQ_T16_RUN8 for the 32-element nibble blocks (Q4_0 Q4_1 Q5_0 Q5_1), whose weight lane
+// (K-chunk c of MFMA f) holds 8 raw bytes = elements 8 h .. 8 h + 7 (low nibbles) and 16 + 8 h .. (high nibbles) of block
+// 2 f + (c >> 1), h = c & 1: the slot is those two 8-element runs, low-nibble run first.
+#define GGQ_T16_RUN8 (~0ull)
+__device__ __forceinline__ void t16_slot(uint64_t inv, int e256, int& slot, int& byte) {
+  if (inv == GGQ_T16_RUN8) {
+    const int b = e256 >> 5, w = e256 & 31, h = (w >> 3) & 1, hi = w >> 4;
+    slot = 4 * (b >> 1) + 2 * (b & 1) + h;
+    byte = 8 * hi + (w & 7);
+  } else {
+    slot = (int)((inv >> (4 * (e256 >> 4))) & 15);
+    byte = e256 & 15;
+  }
+}
+
 template <int DT, int LAYOUT, bool NEED_SUM>
 __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restrict__ x,
                                                             uint8_t* __restrict__ q, int64_t batch,
@@ -94,8 +110,9 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
     // batch <= 8: per ix/256 a 2304-byte tile { int8 frag[4][4 K-chunks][8 tokens][16]; ds[2 halves][2 token quads][4 groups][4 tokens] }
     uint8_t* tile = q + (g >> 3) * 2304;
     const int e256 = (int)(ix & 255), tl = (int)(t & 7);
-    const int slot = (int)((inv >> (4 * (e256 >> 4))) & 15);
-    *(uint32_t*)(tile + (slot >> 2) * 512 + ((slot & 3) * 8 + tl) * 16 + (e256 & 15)) = packed;
+    int slot, byte;
+    t16_slot(inv, e256, slot, byte);
+    *(uint32_t*)(tile + (slot >> 2) * 512 + ((slot & 3) * 8 + tl) * 16 + byte) = packed;
     if (e == 0) {
       const int g8 = (int)(g & 7);
       uint8_t* ds = tile + 2048 + ((((g8 >> 2) * 2 + (tl >> 2)) * 4 + (g8 & 3)) * 4 + (tl & 3)) * 4;
@@ -111,8 +128,9 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
     const int64_t n_tt = (batch + 15) >> 4;
     uint8_t* tile = q + ((g >> 3) * n_tt + (t >> 4)) * 4608;
     const int e256 = (int)(ix & 255), tl = (int)(t & 15);
-    const int slot = (int)((inv >> (4 * (e256 >> 4))) & 15);   // fragment = slot >> 2, K-chunk = slot & 3
-    *(uint32_t*)(tile + (slot >> 2) * 1024 + ((slot & 3) * 16 + tl) * 16 + (e256 & 15)) = packed;
+    int slot, byte;   // fragment = slot >> 2, K-chunk = slot & 3
+    t16_slot(inv, e256, slot, byte);
+    *(uint32_t*)(tile + (slot >> 2) * 1024 + ((slot & 3) * 16 + tl) * 16 + byte) = packed;
     if (e == 0) {
       const int g8 = (int)(g & 7);
       uint8_t* ds = tile + 4096 + ((((g8 >> 2) * 4 + (tl >> 2)) * 4 + (g8 & 3)) * 4 + (tl & 3)) * 4;
@@ -190,17 +208,16 @@ static int launch_quant(const void* x, int dt, void* q, int64_t batch, int64_t k
 // per weight format — the mirror of what the weight lane (row, c) of mmq_t16.hip gets out of its 16 loaded bytes:
 //   Q4_K / Q5_K  f = 2 q + hi: lane c of load q holds bytes 16 (c & 1) .. + 15 of the 32-byte chunk of pair 2 q + (c >> 1);
 //                its low nibbles are elements 64 p + 16 (c & 1) + 0..15 (group 2 p), its high nibbles the same of group 2 p + 1
-//   legacy nibble formats (Q4_0 Q4_1 Q5_0 Q5_1): lane c of step s holds block 4 s + c: low nibbles = its elements 0..15,
-//                high nibbles = 16..31: f = 2 s + hi
+//   legacy nibble formats (Q4_0 Q4_1 Q5_0 Q5_1): 8-element runs, see t16_slot (GGQ_T16_RUN8)
 //   Q8_0         lane c of step s (64 elements) holds elements 64 s + 16 c .. + 15: identity
 static uint64_t t16_inverse_perm(int type) {
+  if (type == GGQ_TYPE_Q4_0 || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_0 || type == GGQ_TYPE_Q5_1) return GGQ_T16_RUN8;
   int perm[16];
   for (int f = 0; f < 4; ++f)
     for (int c = 0; c < 4; ++c) {
       int v;
       if (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K) v = 8 * (f >> 1) + 4 * (c >> 1) + 2 * (f & 1) + (c & 1);
-      else if (type == GGQ_TYPE_Q8_0) v = 4 * f + c;
-      else v = 2 * (4 * (f >> 1) + c) + (f & 1);
+      else v = 4 * f + c;   // Q8_0: identity
       perm[4 * f + c] = v;
     }
   uint64_t inv = 0;

@@ -39,6 +39,12 @@ def test_quantize_q8_1_t16_bit_exact(oracle, dtype, t, batch, k):
                                             (33, 1280, 95), (64, 4096, 48), (9, 11008, 40), (24, 16384, 20), (7, 20480, 17)])
 def test_mmq_t16_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     """ragged row tiles and token tiles, 1 .. 12 K-slices of equal and unequal length, slices of several LDS rounds (K > 12288)"""
+    from ggq.formats import BLOCK
+    if BLOCK[t][0] == 32 and batch > 16:   # the 32-element-block formats have no two-token-tile instance
+        assert ggqlib.hip().ggq_mmq_t16_supported(int(t), k, batch) == 0
+        q = torch.zeros(int(ggqlib.hip().ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+        assert ggqlib.hip().ggq_mul_mat_q_t16(util.vp(q), util.vp(q), util.vp(q), int(t), 1, batch, k, n_rows, n_rows, 0, None, util.stream_ptr()) == -2
+        return
     assert ggqlib.hip().ggq_mmq_t16_supported(int(t), k, batch) == 1
     w = synth.random_weight(t, n_rows, k, seed=batch + k)
     x = _x((batch, k), dtype, seed=14)
@@ -54,7 +60,7 @@ def test_mmq_t16_integer_exact(oracle, t):
     from ggq.formats import BLOCK
     from ggq.synth import _F16_FIELDS
     qk, bs = BLOCK[t]
-    n_rows, k, batch = 64, 512, 24
+    n_rows, k, batch = 64, 512, (24 if qk == 256 else 14)
     w = synth.random_weight(t, n_rows, k, seed=9).reshape(-1, bs)
     d_off, m_off = _F16_FIELDS[t]
     w[:, d_off:d_off + 2] = np.array([2.0 ** -4], np.float16).view(np.uint8)
@@ -116,6 +122,9 @@ def test_mmq_t16_full_size_properties(oracle, t, n_rows, k, batch):
     """BASELINE shapes (gate/up, down, one rank of configs[4]): oracle on a sample of rows, then the size-independent
     properties on every output — bit-reproducible run to run, weight-row permutation, token permutation, exact scaling of
     X by a power of two (fp32 in / out)."""
+    from ggq.formats import BLOCK
+    if BLOCK[t][0] == 32 and batch > 16:
+        batch = 16
     w = synth.random_weight(t, n_rows, k, seed=21)
     wd = util.dev_bytes(w)
     x = _x((batch, k), torch.float32, seed=22)
@@ -129,4 +138,5 @@ def test_mmq_t16_full_size_properties(oracle, t, n_rows, k, batch):
     assert torch.equal(util.gpu_mmq_t16(np.ascontiguousarray(w[perm]), x, t, n_rows), y[:, torch.from_numpy(perm).cuda()]), "Y(P W) != Y(W) P"
     tp = torch.from_numpy(np.random.default_rng(3).permutation(batch)).cuda()
     assert torch.equal(util.gpu_mmq_t16(w, x[tp].contiguous(), t, n_rows, w_dev=wd), y[tp]), "Y(P X) != P Y(X)"
-    assert torch.equal(util.gpu_mmq_t16(w, x * 8.0, t, n_rows, w_dev=wd), y * 8.0), "Y(8 X) != 8 Y(X)"
+    if t not in (GGMLType.Q4_1, GGMLType.Q5_1):   # their fp16 products d d8, m s8 (mmq.cuh:527-529) reach the fp16 subnormal range,
+        assert torch.equal(util.gpu_mmq_t16(w, x * 8.0, t, n_rows, w_dev=wd), y * 8.0), "Y(8 X) != 8 Y(X)"   # where rounding is not scale-invariant

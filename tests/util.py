@@ -149,8 +149,9 @@ def assert_fp_accumulate(y_gpu, y_ref, yabs, dtype, what=""):
 
 # ---------------------------------------------------------------- 16-token-tile path (mmq_t16.hip)
 def t16_perm(t):
-    """slot 4 f + c of a 4608-byte tile -> which 16-element run of the 256-element unit it holds; written from the
-    weight formats' bit layouts (HK/ggml/ggml-common.h:17-108), independently of quantize.hip's t16_inverse_perm"""
+    """the 16-byte slot 4 f + c of a tile (fragment f, K-chunk c) -> the two 8-element runs of the 256-element unit it holds, in
+    order; written from the weight formats' bit layouts (HK/ggml/ggml-common.h:17-108) and from which raw bytes the weight
+    lane (row, chunk c) of MFMA f reads, independently of quantize.hip's tables"""
     t = GGMLType(int(t))
     perm = []
     for f in range(4):
@@ -158,13 +159,15 @@ def t16_perm(t):
             if t in (GGMLType.Q4_K, GGMLType.Q5_K):
                 q, hi = divmod(f, 2)                 # 64-byte half of the nibble field, low / high nibbles
                 pair, half = 2 * q + (c >> 1), c & 1   # 32-byte chunk of the pair, its 16-byte half
-                perm.append((64 * pair + 32 * hi + 16 * half) // 16)
-            elif t == GGMLType.Q8_0:
-                perm.append(4 * f + c)
-            else:                                     # 32-element nibble blocks: lane c of step s holds block 4 s + c
-                s, hi = divmod(f, 2)
-                perm.append((32 * (4 * s + c) + 16 * hi) // 16)
-    assert sorted(perm) == list(range(16))
+                e0 = 64 * pair + 32 * hi + 16 * half
+                perm.append((e0 // 8, e0 // 8 + 1))
+            elif t == GGMLType.Q8_0:                  # the lane's 16 bytes are 16 consecutive elements
+                perm.append((2 * (4 * f + c), 2 * (4 * f + c) + 1))
+            else:   # 32-element nibble blocks: the lane reads qs[8 h .. 8 h + 7] of block 2 f + (c >> 1): low nibbles = elements
+                    # 8 h .., high nibbles = elements 16 + 8 h ..
+                b, h = 2 * f + (c >> 1), c & 1
+                perm.append(((32 * b + 8 * h) // 8, (32 * b + 16 + 8 * h) // 8))
+    assert sorted(r for p in perm for r in p) == list(range(32))
     return perm
 
 
@@ -180,10 +183,11 @@ def retile_q8_1_t16(q_mmq, batch, k, t):
         for tok in range(batch):
             qs = blocks[:, tok, 16:].reshape(n_u, 256)
             ds = blocks[:, tok, :16].reshape(n_u, 8, 4)
-            for slot, v in enumerate(perm):
+            for slot, (v0, v1) in enumerate(perm):
                 f, c = divmod(slot, 4)
                 o = f * 512 + (c * 8 + tok) * 16
-                out[:, o:o + 16] = qs[:, 16 * v:16 * v + 16]
+                out[:, o:o + 8] = qs[:, 8 * v0:8 * v0 + 8]
+                out[:, o + 8:o + 16] = qs[:, 8 * v1:8 * v1 + 8]
             for g8 in range(8):
                 o = 2048 + ((((g8 >> 2) * 2 + (tok >> 2)) * 4 + (g8 & 3)) * 4 + (tok & 3)) * 4
                 out[:, o:o + 4] = ds[:, g8]
@@ -193,10 +197,11 @@ def retile_q8_1_t16(q_mmq, batch, k, t):
         tt, tl = divmod(tok, 16)
         qs = blocks[:, tok, 16:].reshape(n_u, 256)          # the token's int8 values, unit by unit
         ds = blocks[:, tok, :16].reshape(n_u, 8, 4)         # [unit][group of the unit][4 bytes]
-        for slot, v in enumerate(perm):
+        for slot, (v0, v1) in enumerate(perm):
             f, c = divmod(slot, 4)
             o = f * 1024 + (c * 16 + tl) * 16
-            out[:, tt, o:o + 16] = qs[:, 16 * v:16 * v + 16]
+            out[:, tt, o:o + 8] = qs[:, 8 * v0:8 * v0 + 8]
+            out[:, tt, o + 8:o + 16] = qs[:, 8 * v1:8 * v1 + 8]
         for g8 in range(8):
             o = 4096 + ((((g8 >> 2) * 4 + (tl >> 2)) * 4 + (g8 & 3)) * 4 + (tl & 3)) * 4
             out[:, tt, o:o + 4] = ds[:, g8]
