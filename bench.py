@@ -655,6 +655,14 @@ def secondary_configs(L, dev, w_q4k, w_q4k_ring, x128, scratch, args):
         rec(f"mmq_Q4_K_batch{bb}",
             lambda b, bb=bb, xb=xb: L.ggq_mul_mat_q(vp(b[0]), vp(xb), vp(y128), Q4_K, 1, bb, K_DIM, N_DIM, vp(scratch), cur_stream()),
             [rings[Q4_K]], algo_bytes_matmul(Q4_K, N_DIM, K_DIM, bb), 2.0 * bb * N_DIM * K_DIM, iters=52)
+    # ... and the 32-element-block formats on the same kernel (batch <= 16; routed by shape)
+    x16 = x128[:16].contiguous()
+    rec("mmq_Q4_0_batch8",
+        lambda b: L.ggq_mul_mat_q(vp(b[0]), vp(x8), vp(y128), Q4_0, 1, 8, K_DIM, N_DIM, vp(scratch), cur_stream()),
+        [rings[Q4_0]], algo_bytes_matmul(Q4_0, N_DIM, K_DIM, 8), 2.0 * 8 * N_DIM * K_DIM, iters=52)
+    rec("mmq_Q8_0_batch16",
+        lambda b: L.ggq_mul_mat_q(vp(b[0]), vp(x16), vp(y128), Q8_0, 1, 16, K_DIM, N_DIM, vp(scratch), cur_stream()),
+        [rings[Q8_0]], algo_bytes_matmul(Q8_0, N_DIM, K_DIM, 16), 2.0 * 16 * N_DIM * K_DIM, iters=52)
     # north_star: Q8_0 at batch 1 too (MMVQ)
     rec("mmvq_Q8_0_batch1",
         lambda b: L.ggq_mul_mat_vec_q(vp(b[0]), vp(x1), vp(y1), Q8_0, 1, K_DIM, N_DIM, vp(sc1), cur_stream()),
