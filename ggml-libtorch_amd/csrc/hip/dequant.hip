@@ -290,7 +290,7 @@ template <int T> struct IqDecode {
   static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
     uint32_t lo, hi;
     float mul;
-    IqRun<T>::get(b, sub >> 2, sub & 3, lo, hi, mul);
+    IqRun<T>::get(IqGrid<T>::table(), b, sub >> 2, sub & 3, lo, hi, mul);
     const float d = bits_h_f32(ld_u16(b)) * mul * IqRun<T>::post;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -323,7 +323,7 @@ template <> struct Decode<GGQ_TYPE_IQ1_S> {
     const int ib = sub >> 2, il = sub & 3;
     const uint32_t qh = ld_u16(b + off::IQ1_S_QH + 2 * ib);
     uint32_t lo, hi;
-    iq1_grid(b[off::IQ1_S_QS + 4 * ib + il] | (((qh >> (3 * il)) & 7) << 8), lo, hi);
+    iq1_grid(ggq_iq1s_grid_gpu, b[off::IQ1_S_QS + 4 * ib + il] | (((qh >> (3 * il)) & 7) << 8), lo, hi);
     const float delta = (qh & 0x8000) ? -1.0f - IQ1_DELTA : -1.0f + IQ1_DELTA;
     iq1_emit(lo, hi, bits_h_f32(ld_u16(b + off::IQ1_S_D)) * (float)(2 * ((qh >> 12) & 7) + 1), delta, y);
   }
@@ -335,7 +335,7 @@ template <> struct Decode<GGQ_TYPE_IQ1_M> {
     const uint32_t sc = ld_u16(b + off::IQ1_M_SC + 2 * (ib16 >> 2));
     const uint32_t qh = b[off::IQ1_M_QH + ib16] >> (4 * (il & 1));
     uint32_t lo, hi;
-    iq1_grid(b[off::IQ1_M_QS + 4 * ib + il] | ((qh & 7) << 8), lo, hi);
+    iq1_grid(ggq_iq1s_grid_gpu, b[off::IQ1_M_QS + 4 * ib + il] | ((qh & 7) << 8), lo, hi);
     const float delta = (qh & 0x08) ? -1.0f - IQ1_DELTA : -1.0f + IQ1_DELTA;
     iq1_emit(lo, hi, iq1m_super_scale(b) * (float)(2 * ((sc >> (3 * (ib16 & 3))) & 7) + 1), delta, y);
   }

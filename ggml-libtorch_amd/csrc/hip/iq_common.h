@@ -27,14 +27,29 @@ __device__ __forceinline__ uint32_t iq_sign_mask4(uint32_t bits) { return (((bit
 // per byte: m == 0xFF ? -g : g, for grid magnitudes g in 1..0x7F (never 0: g ^ 0xFF + 1 cannot carry into the next byte)
 __device__ __forceinline__ uint32_t iq_apply_signs4(uint32_t g4, uint32_t m4) { return (g4 ^ m4) + (m4 & 0x01010101u); }
 
+// which codebook a format reads, for kernels that stage it in LDS (the GEMV: a per-lane lookup in global memory touches up to
+// 64 cache lines per wave-level load; in LDS it is one ds_read)
+template <int T> struct IqGrid { static constexpr int BYTES = 0; static __device__ __forceinline__ const void* table() { return nullptr; } };
+#define GGQ_IQ_GRID(T, TAB) \
+  template <> struct IqGrid<T> { static constexpr int BYTES = (int)sizeof(TAB); static __device__ __forceinline__ const void* table() { return TAB; } }
+GGQ_IQ_GRID(GGQ_TYPE_IQ2_XXS, ggq_iq2xxs_grid);
+GGQ_IQ_GRID(GGQ_TYPE_IQ2_XS, ggq_iq2xs_grid);
+GGQ_IQ_GRID(GGQ_TYPE_IQ2_S, ggq_iq2s_grid);
+GGQ_IQ_GRID(GGQ_TYPE_IQ3_XXS, ggq_iq3xxs_grid);
+GGQ_IQ_GRID(GGQ_TYPE_IQ3_S, ggq_iq3xs_grid);
+GGQ_IQ_GRID(GGQ_TYPE_IQ1_S, ggq_iq1s_grid_gpu);
+GGQ_IQ_GRID(GGQ_TYPE_IQ1_M, ggq_iq1s_grid_gpu);
+#undef GGQ_IQ_GRID
+
 // the eight signed int8 values of 8-element run `il` of 32-element sub-block `ib` as two dwords, and the sub-block's
-// float scale factor (the reference's `d` without x.d), per format
+// float scale factor (the reference's `d` without x.d), per format.  `grid` = the format's codebook (IqGrid<T>::table() or a
+// copy of it in LDS).
 template <int T> struct IqRun;
 
 template <> struct IqRun<GGQ_TYPE_IQ2_XXS> {
-  static __device__ __forceinline__ void get(const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
+  static __device__ __forceinline__ void get(const void* grid, const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
     const u32x2_a2 q = ld_u32x2(b + off::IQ2_XXS_QS + 8 * ib);   // {4 grid indices, scale << 28 | 4 x 7 sign bits}
-    const uint64_t g = ggq_iq2xxs_grid[(q.v[0] >> (8 * il)) & 0xFF];
+    const uint64_t g = ((const uint64_t*)grid)[(q.v[0] >> (8 * il)) & 0xFF];
     const uint32_t s = iq_signs8((q.v[1] >> (7 * il)) & 127);
     lo = iq_apply_signs4((uint32_t)g, iq_sign_mask4(s));
     hi = iq_apply_signs4((uint32_t)(g >> 32), iq_sign_mask4(s >> 4));
@@ -43,9 +58,9 @@ template <> struct IqRun<GGQ_TYPE_IQ2_XXS> {
   static constexpr float post = 0.25f;
 };
 template <> struct IqRun<GGQ_TYPE_IQ2_XS> {
-  static __device__ __forceinline__ void get(const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
+  static __device__ __forceinline__ void get(const void* grid, const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
     const uint32_t q2 = ld_u16(b + off::IQ2_XS_QS + 8 * ib + 2 * il);
-    const uint64_t g = ggq_iq2xs_grid[q2 & 511];
+    const uint64_t g = ((const uint64_t*)grid)[q2 & 511];
     const uint32_t s = iq_signs8(q2 >> 9);
     lo = iq_apply_signs4((uint32_t)g, iq_sign_mask4(s));
     hi = iq_apply_signs4((uint32_t)(g >> 32), iq_sign_mask4(s >> 4));
@@ -54,9 +69,9 @@ template <> struct IqRun<GGQ_TYPE_IQ2_XS> {
   static constexpr float post = 0.25f;
 };
 template <> struct IqRun<GGQ_TYPE_IQ2_S> {
-  static __device__ __forceinline__ void get(const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
+  static __device__ __forceinline__ void get(const void* grid, const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
     const uint32_t idx = b[off::IQ2_S_QS + 4 * ib + il] | (((uint32_t)b[off::IQ2_S_QH + ib] << (8 - 2 * il)) & 0x300);
-    const uint64_t g = ggq_iq2s_grid[idx];
+    const uint64_t g = ((const uint64_t*)grid)[idx];
     const uint32_t s = b[off::IQ2_S_SIGNS + 4 * ib + il];
     lo = iq_apply_signs4((uint32_t)g, iq_sign_mask4(s));
     hi = iq_apply_signs4((uint32_t)(g >> 32), iq_sign_mask4(s >> 4));
@@ -65,30 +80,30 @@ template <> struct IqRun<GGQ_TYPE_IQ2_S> {
   static constexpr float post = 0.25f;
 };
 template <> struct IqRun<GGQ_TYPE_IQ3_XXS> {
-  static __device__ __forceinline__ void get(const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
+  static __device__ __forceinline__ void get(const void* grid, const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
     const uint32_t q3 = ld_u16(b + off::IQ3_XXS_QS + 8 * ib + 2 * il);
     const uint32_t aux = ld_u32(b + off::IQ3_XXS_GAS + 4 * ib);
     const uint32_t s = iq_signs8((aux >> (7 * il)) & 127);
-    lo = iq_apply_signs4(ggq_iq3xxs_grid[q3 & 0xFF], iq_sign_mask4(s));
-    hi = iq_apply_signs4(ggq_iq3xxs_grid[q3 >> 8], iq_sign_mask4(s >> 4));
+    lo = iq_apply_signs4(((const uint32_t*)grid)[q3 & 0xFF], iq_sign_mask4(s));
+    hi = iq_apply_signs4(((const uint32_t*)grid)[q3 >> 8], iq_sign_mask4(s >> 4));
     mul = 0.5f + (float)(aux >> 28);
   }
   static constexpr float post = 0.5f;
 };
 template <> struct IqRun<GGQ_TYPE_IQ3_S> {
-  static __device__ __forceinline__ void get(const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
+  static __device__ __forceinline__ void get(const void* grid, const uint8_t* b, int ib, int il, uint32_t& lo, uint32_t& hi, float& mul) {
     const uint32_t q3 = ld_u16(b + off::IQ3_S_QS + 8 * ib + 2 * il), qh = b[off::IQ3_S_QH + ib];
     const uint32_t s = b[off::IQ3_S_SIGNS + 4 * ib + il];
-    lo = iq_apply_signs4(ggq_iq3xs_grid[(q3 & 0xFF) | ((qh << (8 - 2 * il)) & 256)], iq_sign_mask4(s));
-    hi = iq_apply_signs4(ggq_iq3xs_grid[(q3 >> 8) | ((qh << (7 - 2 * il)) & 256)], iq_sign_mask4(s >> 4));
+    lo = iq_apply_signs4(((const uint32_t*)grid)[(q3 & 0xFF) | ((qh << (8 - 2 * il)) & 256)], iq_sign_mask4(s));
+    hi = iq_apply_signs4(((const uint32_t*)grid)[(q3 >> 8) | ((qh << (7 - 2 * il)) & 256)], iq_sign_mask4(s >> 4));
     mul = 0.5f + (float)((b[off::IQ3_S_SC + (ib >> 1)] >> (4 * (ib & 1))) & 0xF);
   }
   static constexpr float post = 0.5f;
 };
 
 // IQ1_S / IQ1_M: eight nibble values 0..2 (two dwords of bytes), the run's delta and integer scale
-__device__ __forceinline__ void iq1_grid(uint32_t idx11, uint32_t& lo, uint32_t& hi) {
-  const uint32_t g = ggq_iq1s_grid_gpu[idx11];
+__device__ __forceinline__ void iq1_grid(const void* grid, uint32_t idx11, uint32_t& lo, uint32_t& hi) {
+  const uint32_t g = ((const uint32_t*)grid)[idx11];
   lo = g & 0x0F0F0F0Fu;
   hi = (g >> 4) & 0x0F0F0F0Fu;
 }

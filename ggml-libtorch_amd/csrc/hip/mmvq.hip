@@ -47,6 +47,7 @@ struct ActLds {
   const float* xd;     // [K/32]  d8
   const float* xs;     // [K/32]  s8 (fp16-rounded Σx, as stored by quantize_q8_1)
   const int* xi16;     // [K/16]  Σ q8 over each 16 elements (exact)
+  const void* grid;    // the IQ format's codebook, staged in LDS by the kernel (nullptr for the other formats)
 };
 
 __device__ __forceinline__ v4i lds_ld16(const int8_t* p) { return *(const v4i*)p; }
@@ -396,7 +397,7 @@ template <int T> struct IqUnitDot {   // IQ2_XXS, IQ3_XXS, IQ3_S: one scale per 
     for (int il = 0; il < 4; ++il) {
       uint32_t lo, hi;
       float m;
-      IqRun<T>::get(b, ib, il, lo, hi, m);
+      IqRun<T>::get(A.grid, b, ib, il, lo, hi, m);
       sumi[il >> 1] += iq_dot8(lo, hi, A.xq + 32 * u + 8 * il);
       mul[il >> 1] = m;
     }
@@ -427,7 +428,7 @@ template <> struct UnitDot<GGQ_TYPE_IQ1_S> {   // vecdotq.cuh:750-781
 #pragma unroll
     for (int il = 0; il < 4; ++il) {
       uint32_t lo, hi;
-      iq1_grid(((qs >> (8 * il)) & 0xFF) | (((qh >> (3 * il)) & 7) << 8), lo, hi);
+      iq1_grid(A.grid, ((qs >> (8 * il)) & 0xFF) | (((qh >> (3 * il)) & 7) << 8), lo, hi);
       sumi += iq_dot8(lo, hi, A.xq + 32 * u + 8 * il);
     }
     const float d1q = bits_h_f32(ld_u16(b)) * (float)(((qh >> 11) & 0x0E) + 1);
@@ -448,7 +449,7 @@ template <> struct UnitDot<GGQ_TYPE_IQ1_M> {   // vecdotq.cuh:783-826
     for (int il = 0; il < 4; ++il) {
       const uint32_t qhl = (qh2 >> (8 * (il >> 1))) >> (4 * (il & 1));
       uint32_t lo, hi;
-      iq1_grid(((qs >> (8 * il)) & 0xFF) | ((qhl & 7) << 8), lo, hi);
+      iq1_grid(A.grid, ((qs >> (8 * il)) & 0xFF) | ((qhl & 7) << 8), lo, hi);
       const v2i a = *(const v2i*)(A.xq + 32 * u + 8 * il);
       sumi[il >> 1] = sdot4((int)hi, a[1], sdot4((int)lo, a[0], sumi[il >> 1]));
       const float delta = -1.0f + IQ1_DELTA - (float)(qhl & 0x08) * (2.0f * IQ1_DELTA / 0x08);
@@ -463,7 +464,8 @@ template <> struct UnitDot<GGQ_TYPE_IQ1_M> {   // vecdotq.cuh:783-826
 };
 
 // LDS bytes for a row of k activations: int8[k] + float[k/32]*2 + int[k/16]
-static inline size_t mmvq_lds_bytes(int64_t k) { return (size_t)k + (size_t)(k / 32) * 8 + (size_t)(k / 16) * 4; }
+// x as int8 + d8 / s8 floats + per-16 integer sums (k % 32 == 0: a multiple of 16 bytes), then the IQ codebook
+static inline size_t mmvq_lds_bytes(int64_t k, int grid_bytes = 0) { return (size_t)k + (size_t)(k / 32) * 8 + (size_t)(k / 16) * 4 + (size_t)grid_bytes; }
 
 // FUSED: q8 is the activation row itself (dtype DT); every workgroup quantises it into LDS with the
 // arithmetic of quantize.hip (bit-identical d, q, sum) while its first weight bytes are in flight —
@@ -571,6 +573,11 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
       xs[g] = bits_h_f32(ds >> 16);
     }
   }
+  if constexpr (IqGrid<T>::BYTES != 0) {   // the codebook: 1 - 8 KB, 16 bytes per thread and pass
+    v4i* lg = (v4i*)(xi16 + k / 16);
+    const v4i* gg = (const v4i*)IqGrid<T>::table();
+    for (int i = threadIdx.x; i < IqGrid<T>::BYTES / 16; i += FUSED ? 1024 : 256) lg[i] = gg[i];
+  }
   VSTAMP(1);
   __syncthreads();
   VSTAMP(2);
@@ -584,7 +591,7 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
     }
     __syncthreads();
   }
-  const ActLds A{xq, xd, xs, xi16};
+  const ActLds A{xq, xd, xs, xi16, IqGrid<T>::BYTES ? (const void*)(xi16 + k / 16) : nullptr};
 
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (FUSED ? 16 : 4) + (threadIdx.x >> 6);
@@ -677,7 +684,7 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
   // rows in flight per wave: three in the fused kernel (a wave owns 2.7 rows at 11008 rows on 4096 waves: all of them go
   // out at once — Q4_0 10.7 -> 10.0 us cold, 7.9 -> 7.7 warm), two for Q8_0 (34-byte blocks: 15.3 vs 15.8 us cold)
   constexpr int ROWS = !FUSED ? 2 : (T == GGQ_TYPE_Q8_0 ? 2 : GGQ_MMVQ_ROWS);
-  const size_t lds = mmvq_lds_bytes(k);
+  const size_t lds = mmvq_lds_bytes(k, IqGrid<T>::BYTES);
   if (lds > 160 * 1024) return GGQ_ERR_SHAPE;
   // many short-lived waves keep more weight bytes in flight (measured: 2 rows per wave beats
   // 4-8 at N = 11008); rows_per_wave = n / 8192, even, in [2, 16]
