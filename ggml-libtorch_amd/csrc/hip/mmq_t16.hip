@@ -68,10 +68,11 @@ __device__ __forceinline__ float t16_epilogue(float v, int epi, const void* aux,
 
 template <int T> struct T16Fmt {
   static_assert(T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K || T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 ||
-                T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1, "format");
+                T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1 || T == GGQ_TYPE_Q6_K, "format");
+  static constexpr bool k6 = T == GGQ_TYPE_Q6_K;             // 210-byte super-blocks, one int8 scale per 16 elements
   static constexpr bool legacy = Fmt<T>::QK == 32;           // 32-element blocks {fp16 d [, fp16 m] [, u32 qh], qs}, no super-block header
-  static constexpr int UB = 256 / Fmt<T>::QK * Fmt<T>::BS;   // bytes of one 256-element unit of a weight row — a multiple of 16 for
-                                                             // every format here (eight 18 / 20 / 22 / 24 / 34-byte blocks: 144 .. 272)
+  static constexpr int UB = 256 / Fmt<T>::QK * Fmt<T>::BS;   // bytes of one 256-element unit of a weight row — a multiple of 16
+                                                             // (eight 18 / 20 / 22 / 24 / 34-byte blocks: 144 .. 272) except Q6_K's 210
   static constexpr int QS = T == GGQ_TYPE_Q4_K ? off::Q4_K_QS : T == GGQ_TYPE_Q5_K ? off::Q5_K_QS : 2;
   static constexpr bool has_qh = T == GGQ_TYPE_Q5_K;
   // 32-element blocks
@@ -87,7 +88,7 @@ template <int T> struct T16Fmt {
 
 // wave-private LDS (bytes): W [16 rows][MAXU units] raw bytes | TAB scale tables
 template <int T, bool M8, int NTT, int MAXU> struct T16Lds {
-  static constexpr int SB = MAXU * T16Fmt<T>::UB;          // slice bytes of one row
+  static constexpr int SB = (MAXU * T16Fmt<T>::UB + 15) / 16 * 16;   // LDS pitch of one row's slice (whole 16-byte DMA chunks)
   static constexpr int NI = (16 * SB + 1023) / 1024;       // DMA instructions (1 KB each) of the weight image (the last may be partial:
                                                            // its surplus lanes repeat the final chunk into the padding)
   static constexpr int TT = M8 ? 256 : 512;                // scale table of one (unit, token tile)
@@ -124,12 +125,17 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
   uint8_t* wl = lds + ks * L::WAVE;
   T16_STAMP(0);
 
+  int k6_shift = 0;                                        // (Q6_K) see request_round
+  const bool k6_last_row = n0 + min(j, rmax) == n_rows - 1;
+  // (Q6_K) descriptor over the whole weight tensor (the launcher admits it below 4 GiB): the shifted copy of the last row may
+  // start in the row before this tile
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((uint32_t)n_rows * row_bytes), 0x00020000);
   // activations: one descriptor over the scratch, scalar tile offsets, the lane's 16 bytes of a fragment
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q8, 0, (int)0x7FFFFFFF, 0x00020000);
   auto tile_off = [&](int u, int jj) { return (uint32_t)((u * n_tt + min(tt0 + jj, n_tt - 1)) * L::TILE); };
   // M8: lane (A row j, K-chunk c) holds token j & 7 in the chunks of its row half's group pair and ZERO in the others
   // (offset beyond the descriptor's range: the load returns 0 and touches no memory)
-  const uint32_t frag_voff = !M8 ? (uint32_t)lane * 16 : ((j < 8) == (c < 2)) ? (uint32_t)(c * 8 + (j & 7)) * 16 : 0x80000000u;
+  const uint32_t frag_voff = !M8 ? (uint32_t)lane * 16 : (F::k6 || (j < 8) == (c < 2)) ? (uint32_t)(c * 8 + (j & 7)) * 16 : 0x80000000u;
   auto ld_frag = [&](uint32_t toff, int f) {
     const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)frag_voff, (int)(toff + f * L::FRAG), 0);
     return v4i{(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
@@ -163,6 +169,21 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
         }
     }
     constexpr int CPR = SB / 16, CPU = UB / 16;   // 16-byte chunks per row slice / per unit
+    if constexpr (F::k6) {
+      // 210-byte units: a slice is not a whole number of chunks and starts at a 2-byte aligned address.  The copy runs along
+      // the row from the slice's first byte and reads SB bytes: past the slice that is the next slice or the next row — except
+      // in the tensor's LAST row, whose copy is shifted down by `k6_shift` bytes so that it ends with the row (the reader adds
+      // the shift back; LDS reads need no alignment).  The buffer descriptor ends with the tensor in any case.
+      k6_shift = max(0, ub * UB + SB - (int)row_bytes);
+#pragma unroll
+      for (int i = 0; i < L::NI; ++i) {
+        const int n = min(64 * i + lane, 16 * CPR - 1);
+        const int row = min(n / CPR, rmax), col = n - (n / CPR) * CPR;
+        const uint32_t voff = (uint32_t)(n0 + row) * row_bytes + (uint32_t)ub * UB + 16u * (uint32_t)col - (n0 + row == n_rows - 1 ? (uint32_t)k6_shift : 0u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (t16_lptr)(wl + L::W + i * 1024), 16, (int)voff, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < L::NI; ++i) {
       const int n = min(64 * i + lane, 16 * CPR - 1);
@@ -188,7 +209,76 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
 #pragma unroll
   for (int jj = 0; jj < NTT; ++jj) accm[jj] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
   auto compute_unit = [&](int s, const Frags& Fr) {
-    if constexpr (F::legacy) {
+    if constexpr (F::k6) {
+      // ---- Q6_K {ql[128]; qh[64]; int8 scales[16]; fp16 d}: element 128 ip + 32 jq + l = nibble (jq >> 1) of ql[64 ip + 32 (jq & 1) + l]
+      //      | bits 2 jq .. of qh[32 ip + l] << 4, minus 32 (dequantize.cuh:236-253).  Lane (row j, chunk c) of half ip reads
+      //      ql[64 ip + 16 c .. + 15] and qh[32 ip + 16 (c & 1) .. + 15]: its low nibbles are the 16-element sub-block 8 ip + c, its high
+      //      nibbles sub-block 8 ip + 4 + c — operand f = 2 ip + hi holds sub-block 4 f + c in chunk c, the identity order of the
+      //      activation fragments.  Every sub-block has its own int8 scale, so a K = 64 MFMA must not mix chunks: M8 splits an
+      //      operand in two MFMAs (token rows 0-7 take chunk 0 | 2, rows 8-15 chunk 1 | 3), the 16-token form in four with the
+      //      other chunks of B zeroed.  float(C) d8 (d sc) per sub-block (mmq.cuh:1726-1732 re-associated). ----
+      typedef unsigned v4u_a2 __attribute__((ext_vector_type(4), aligned(2)));
+      const uint8_t* blk = wl + L::W + j * SB + s * UB + (k6_last_row ? k6_shift : 0);
+      const float d6 = bits_h_f32(*(const uint16_t*)(blk + off::Q6_K_D));
+      const v4i zero = {0, 0, 0, 0};
+      auto sub32 = [](uint32_t x) { return ((x | 0x80808080u) - 0x20202020u) ^ 0x80808080u; };   // per byte x - 32 as int8 (x <= 63)
+#pragma unroll
+      for (int ip = 0; ip < 2; ++ip) {
+        const v4u_a2 ql = *(const v4u_a2*)(blk + off::Q6_K_QL + 64 * ip + 16 * c);
+        const v4u_a2 qh = *(const v4u_a2*)(blk + off::Q6_K_QH + 32 * ip + 16 * (c & 1));
+        const int jl = c >> 1;
+        v4i B[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          B[0][i] = (int)sub32((ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * jl)) & 0x03030303u) << 4));
+          B[1][i] = (int)sub32(((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * jl + 4)) & 0x03030303u) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int f = 2 * ip + m;
+          if constexpr (M8) {
+            const v4i A = Fr.a[ip][0][m];
+            const bool ka = j < 8 ? c == 0 : c == 1, kb = j < 8 ? c == 2 : c == 3;
+            v4i Aa, Ab;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Aa[i] = ka ? A[i] : 0; Ab[i] = kb ? A[i] : 0; }
+            const v4i Ca = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aa, B[m], zero, 0, 0, 0);   // lane quad c: sub-block 4 f + (c >> 1)
+            const v4i Cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ab, B[m], zero, 0, 0, 0);   //              sub-block 4 f + 2 + (c >> 1)
+            const float dwa = d6 * (float)(int8_t)blk[off::Q6_K_SC + 4 * f + sel], dwb = d6 * (float)(int8_t)blk[off::Q6_K_SC + 4 * f + 2 + sel];
+            const uint8_t* tq = wl + L::TAB + s * 256 + ip * 128 + (c & 1) * 64;   // [token quad][group of the half][token] fp32 d8
+            const v4u_t da = *(const v4u_t*)(tq + (2 * m) * 16), db = *(const v4u_t*)(tq + (2 * m + 1) * 16);
+            const uint32_t ta[4] = {da[0], da[1], da[2], da[3]}, tb[4] = {db[0], db[1], db[2], db[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[0][r] = __builtin_fmaf((float)Ca[r] * as_f32((int)ta[r]), dwa, acc[0][r]);
+              acc[0][r] = __builtin_fmaf((float)Cb[r] * as_f32((int)tb[r]), dwb, acc[0][r]);
+            }
+          } else {
+            v4i Bm[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) Bm[cc][i] = c == cc ? B[m][i] : 0;
+            float dw[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) dw[cc] = d6 * (float)(int8_t)blk[off::Q6_K_SC + 4 * f + cc];
+#pragma unroll
+            for (int jj = 0; jj < NTT; ++jj) {
+              const uint8_t* tq = wl + L::TAB + (jj * ((MAXU + 1) / 2) * 2 + s) * 512 + ip * 256 + c * 64;
+              const v4u_t d0 = *(const v4u_t*)(tq + (2 * m) * 16), d1 = *(const v4u_t*)(tq + (2 * m + 1) * 16);   // tokens 4 c .. + 3, groups 2 m, 2 m + 1 of the half
+              const uint32_t tw[2][4] = {{d0[0], d0[1], d0[2], d0[3]}, {d1[0], d1[1], d1[2], d1[3]}};
+#pragma unroll
+              for (int cc = 0; cc < 4; ++cc) {
+                const v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Fr.a[ip][jj][m], Bm[cc], zero, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[jj][r] = __builtin_fmaf((float)C[r] * as_f32((int)tw[cc >> 1][r]), dw[cc], acc[jj][r]);
+              }
+            }
+          }
+        }
+      }
+      return;
+    } else if constexpr (F::legacy) {
       // ---- 32-element blocks: the unit is eight blocks of row j.  Lane (row j, chunk c) of MFMA m of half q works on block
       //      4 q + 2 m + (c >> 1), h = c & 1:
       //        Q8_0   qs[16 h .. + 15] (a 2-byte aligned ds_read_b128): K order = element order;
@@ -557,7 +647,7 @@ static int launch_t16_dt(const void* w, const void* q8, void* y, int64_t batch, 
   if (batch <= 16) return launch_t16<T, DT, false, 1>(w, q8, y, batch, k, n, ldy, s, ep);
   // two token tiles per wave: the K-quants only (the 32-element-block instances spill 70 - 90 registers; ggq_mmq_t16_supported
   // keeps their batches at 16)
-  if constexpr (T16Fmt<T>::legacy) return GGQ_ERR_SHAPE;
+  if constexpr (T16Fmt<T>::legacy || T16Fmt<T>::k6) return GGQ_ERR_SHAPE;
   else return launch_t16<T, DT, false, 2>(w, q8, y, batch, k, n, ldy, s, ep);
 }
 
@@ -585,6 +675,8 @@ extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type
   if (n_rows == 0 || batch == 0) return GGQ_OK;
   if (!ggq_mmq_t16_supported(type, k, batch)) return ggq_mmq_t16_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
   if (n_rows > 0x7fffffffLL - 64) return GGQ_ERR_SHAPE;
+  if (type == GGQ_TYPE_Q6_K && (n_rows * ggq_row_bytes(type, k) < 1024 || n_rows * ggq_row_bytes(type, k) >= (1ll << 32)))
+    return GGQ_ERR_SHAPE;   // the shifted copy of the last row starts inside the tensor; 32-bit offsets into the whole tensor
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
   const Epi16 ep{epilogue, aux};
@@ -597,6 +689,7 @@ extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type
     case GGQ_TYPE_Q4_1: return launch_t16_t<GGQ_TYPE_Q4_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     case GGQ_TYPE_Q5_0: return launch_t16_t<GGQ_TYPE_Q5_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     case GGQ_TYPE_Q5_1: return launch_t16_t<GGQ_TYPE_Q5_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q6_K: return launch_t16_t<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     default: return GGQ_ERR_TYPE;
   }
 }

@@ -71,7 +71,7 @@ def test_mmq_routing_table():
                     continue
                 assert r in (DOT4, LDS_TILE, STREAM, T16)
                 if r == T16:
-                    assert k % 256 == 0 and 2 <= b <= (32 if BLOCK[t][0] == 256 else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
+                    assert k % 256 == 0 and 2 <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
                 if r == DOT4:
                     assert b <= 8
                 prev = r
@@ -85,7 +85,8 @@ def test_mmq_routing_table():
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == DOT4 and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == STREAM
         assert L.ggq_mmq_route(Q8_0, 17, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 64, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
-        assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 8, k, n) == DOT4
+        assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == DOT4
+        assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8, 16)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
         assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == DOT4
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
@@ -103,6 +104,9 @@ def test_mmq_routing_table():
     assert L.ggq_mmq_route(20, 8, 4096, 64) == NONE   # IQ4_NL: no GEMM
     # 32-bit offsets: a scratch of 2 GiB or more stays off the 16-token-tile kernel
     assert L.ggq_mmq_route(Q4_K, 32, 1 << 26, 64) != T16 and L.ggq_mmq_route(Q4_K, 32, 1 << 21, 64) == T16
+    # Q6_K: the whole tensor within 32-bit offsets and at least 1 KB (its last row's copy is shifted into the row before)
+    assert L.ggq_mmq_route(Q6_K, 8, 256, 4) != T16 and L.ggq_mmq_route(Q6_K, 8, 256, 8) == T16
+    assert L.ggq_mmq_route(Q6_K, 8, 1 << 20, 8192) != T16
 
 
 def test_shipped_code_objects_keep_the_mfma_wait_states():

@@ -163,6 +163,11 @@ def t16_perm(t):
                 perm.append((e0 // 8, e0 // 8 + 1))
             elif t == GGMLType.Q8_0:                  # the lane's 16 bytes are 16 consecutive elements
                 perm.append((2 * (4 * f + c), 2 * (4 * f + c) + 1))
+            elif t == GGMLType.Q6_K:                  # element 128 ip + 32 jq + l <- nibble (jq >> 1) of ql[64 ip + 32 (jq & 1) + l]:
+                ip, hi = divmod(f, 2)                 # operand f = 2 ip + hi, lane chunk c reads ql[64 ip + 16 c ..]: jq & 1 = c >> 1,
+                jq, l0 = 2 * hi + (c >> 1), 16 * (c & 1)   # l = 16 (c & 1) .., and the nibble chosen gives jq >> 1 = hi
+                e0 = 128 * ip + 32 * jq + l0
+                perm.append((e0 // 8, e0 // 8 + 1))
             else:   # 32-element nibble blocks: the lane reads qs[8 h .. 8 h + 7] of block 2 f + (c >> 1): low nibbles = elements
                     # 8 h .., high nibbles = elements 16 + 8 h ..
                 b, h = 2 * f + (c >> 1), c & 1
