@@ -1,5 +1,5 @@
-// mmq_t16.hip — quantised GEMM for the HBM-bound batches (2 .. 32 tokens; Q4_K Q5_K, and Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 up to 16
-// tokens — their operand path is described at `F::legacy` below): 16-row x 16-token MFMA tiles, a wave's whole
+// mmq_t16.hip — quantised GEMM for the HBM-bound batches (2 .. 32 tokens; Q4_K Q5_K, and Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q6_K up to 16
+// tokens — their operand paths are described at `F::legacy` / `F::k6` below): 16-row x 16-token MFMA tiles, a wave's whole
 // share of the weight matrix requested before anything is waited for.  gfx950 only.
 //
 // Same contract as mmq.hip (mul_mat_q, HK/ggml/mmq.cuh:1917-1986, "MMQ canon" of SURVEY §8a: exact int8 contraction per
