@@ -101,7 +101,7 @@ extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
 extern "C" int ggq_mmq_t16_type_supported(int type) {
   switch (type) {
     case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: case GGQ_TYPE_Q8_0:
-    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q6_K: return 1;
+    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q6_K: case GGQ_TYPE_Q3_K: return 1;
     default: return 0;
   }
 }
@@ -109,7 +109,7 @@ extern "C" int ggq_mmq_t16_type_supported(int type) {
 extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
   // 256-element units; 32-bit byte offsets into the activation scratch
   if (!ggq_mmq_t16_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
-  if ((ggq_block_elems(type) == 32 || type == GGQ_TYPE_Q6_K) && batch > 16) return 0;   // the 32-element-block formats and Q6_K have no two-token-tile instance
+  if ((ggq_block_elems(type) == 32 || type == GGQ_TYPE_Q6_K || type == GGQ_TYPE_Q3_K) && batch > 16) return 0;   // the 32-element-block formats and Q6_K have no two-token-tile instance
   if ((uint64_t)ggq_mmq_scratch_bytes(batch, k) >= (1ull << 31)) return 0;
   if ((uint64_t)ggq_row_bytes(type, k) * 16 >= (1ull << 32)) return 0;   // 32-bit byte offsets inside a 16-row weight tile
   return 1;
@@ -141,16 +141,19 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // Q6_K (210-byte super-blocks: unaligned row slices, an MFMA per 16-element sub-block; batch <= 16):
   //   11008 x 4096 b2 14.1/18.6 -> 14.9/16.8   b8 18.5/22.0 -> 14.4/16.8   b16 27.6/31.1 -> 20.2/23.5
   //   3584 x 8192  b8 29.3/31.6 -> 11.0/13.2   b16 29.7/34.9 -> 19.5/22.1     4096 x 11008 b8 41.0/42.7 -> 15.0/18.3
+  // Q3_K (110-byte super-blocks, same scheme; its scale decode keeps the kernel at 15.7 us, so it only pays where the old kernels
+  // do not fill the chip):  11008 x 4096 b8 19.0/21.1 -> 19.0/21.3   b16 21.0/22.9 -> 21.1/23.6
+  //   3584 x 8192 b2 26.5/28.8 -> 12.8/15.3   b8 20.8/23.4 -> 13.3/15.4   b16 22.5/24.7 -> 16.5/19.1     4096 x 11008 b2 35.3/36.7 -> 18.5/20.9   b8 26.9/29.3 -> 18.7/21.2
   int64_t t16_from = 2, t16_to = 0;
   switch (type) {
     case GGQ_TYPE_Q4_K: t16_to = 32; break;
     case GGQ_TYPE_Q5_K: case GGQ_TYPE_Q6_K: t16_to = 16; break;
     case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q8_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
     case GGQ_TYPE_Q5_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 9; break;
-    case GGQ_TYPE_Q5_1: t16_to = n_rows < 8192 ? 16 : 0; break;
+    case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q3_K: t16_to = n_rows < 8192 ? 16 : 0; break;
     default: break;
   }
-  const bool t16_shape_ok = type != GGQ_TYPE_Q6_K || (n_rows * ggq_row_bytes(type, k) >= 1024 && n_rows * ggq_row_bytes(type, k) < (1ll << 32));   // ggq_mul_mat_q_t16's own guards
+  const bool t16_shape_ok = (type != GGQ_TYPE_Q6_K && type != GGQ_TYPE_Q3_K) || (n_rows * ggq_row_bytes(type, k) >= 1024 && n_rows * ggq_row_bytes(type, k) < (1ll << 32));   // ggq_mul_mat_q_t16's own guards
   if (t16_shape_ok && ggq_mmq_t16_supported(type, k, batch) && batch >= t16_from && batch <= t16_to) return GGQ_MMQ_ROUTE_T16;
   // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):
   // the dot4 kernel while it beats the streamed one with the weights coming from HBM, the barrier-coupled LDS-tile

@@ -68,8 +68,10 @@ __device__ __forceinline__ float t16_epilogue(float v, int epi, const void* aux,
 
 template <int T> struct T16Fmt {
   static_assert(T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K || T == GGQ_TYPE_Q8_0 || T == GGQ_TYPE_Q4_0 || T == GGQ_TYPE_Q4_1 ||
-                T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1 || T == GGQ_TYPE_Q6_K, "format");
+                T == GGQ_TYPE_Q5_0 || T == GGQ_TYPE_Q5_1 || T == GGQ_TYPE_Q6_K || T == GGQ_TYPE_Q3_K, "format");
   static constexpr bool k6 = T == GGQ_TYPE_Q6_K;             // 210-byte super-blocks, one int8 scale per 16 elements
+  static constexpr bool k3 = T == GGQ_TYPE_Q3_K;             // 110-byte super-blocks, one 6-bit scale per 16 elements
+  static constexpr bool sub16 = k6 || k3;                    // a scale per 16-element sub-block, units that are no multiple of 16 bytes
   static constexpr bool legacy = Fmt<T>::QK == 32;           // 32-element blocks {fp16 d [, fp16 m] [, u32 qh], qs}, no super-block header
   static constexpr int UB = 256 / Fmt<T>::QK * Fmt<T>::BS;   // bytes of one 256-element unit of a weight row — a multiple of 16
                                                              // (eight 18 / 20 / 22 / 24 / 34-byte blocks: 144 .. 272) except Q6_K's 210
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
   auto tile_off = [&](int u, int jj) { return (uint32_t)((u * n_tt + min(tt0 + jj, n_tt - 1)) * L::TILE); };
   // M8: lane (A row j, K-chunk c) holds token j & 7 in the chunks of its row half's group pair and ZERO in the others
   // (offset beyond the descriptor's range: the load returns 0 and touches no memory)
-  const uint32_t frag_voff = !M8 ? (uint32_t)lane * 16 : (F::k6 || (j < 8) == (c < 2)) ? (uint32_t)(c * 8 + (j & 7)) * 16 : 0x80000000u;
+  const uint32_t frag_voff = !M8 ? (uint32_t)lane * 16 : (F::sub16 || (j < 8) == (c < 2)) ? (uint32_t)(c * 8 + (j & 7)) * 16 : 0x80000000u;
   auto ld_frag = [&](uint32_t toff, int f) {
     const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)frag_voff, (int)(toff + f * L::FRAG), 0);
     return v4i{(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
@@ -169,8 +171,8 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
         }
     }
     constexpr int CPR = SB / 16, CPU = UB / 16;   // 16-byte chunks per row slice / per unit
-    if constexpr (F::k6) {
-      // 210-byte units: a slice is not a whole number of chunks and starts at a 2-byte aligned address.  The copy runs along
+    if constexpr (F::sub16) {
+      // 210- / 110-byte units: a slice is not a whole number of chunks and starts at a 2-byte aligned address.  The copy runs along
       // the row from the slice's first byte and reads SB bytes: past the slice that is the next slice or the next row — except
       // in the tensor's LAST row, whose copy is shifted down by `k6_shift` bytes so that it ends with the row (the reader adds
       // the shift back; LDS reads need no alignment).  The buffer descriptor ends with the tensor in any case.
@@ -209,29 +211,53 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
 #pragma unroll
   for (int jj = 0; jj < NTT; ++jj) accm[jj] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
   auto compute_unit = [&](int s, const Frags& Fr) {
-    if constexpr (F::k6) {
+    if constexpr (F::sub16) {
       // ---- Q6_K {ql[128]; qh[64]; int8 scales[16]; fp16 d}: element 128 ip + 32 jq + l = nibble (jq >> 1) of ql[64 ip + 32 (jq & 1) + l]
       //      | bits 2 jq .. of qh[32 ip + l] << 4, minus 32 (dequantize.cuh:236-253).  Lane (row j, chunk c) of half ip reads
       //      ql[64 ip + 16 c .. + 15] and qh[32 ip + 16 (c & 1) .. + 15]: its low nibbles are the 16-element sub-block 8 ip + c, its high
       //      nibbles sub-block 8 ip + 4 + c — operand f = 2 ip + hi holds sub-block 4 f + c in chunk c, the identity order of the
-      //      activation fragments.  Every sub-block has its own int8 scale, so a K = 64 MFMA must not mix chunks: M8 splits an
-      //      operand in two MFMAs (token rows 0-7 take chunk 0 | 2, rows 8-15 chunk 1 | 3), the 16-token form in four with the
-      //      other chunks of B zeroed.  float(C) d8 (d sc) per sub-block (mmq.cuh:1726-1732 re-associated). ----
+      //      activation fragments.
+      //      Q3_K {hmask[32]; qs[64]; scales[12]; fp16 d}: element 128 ip + 32 jq + l = ((qs[32 ip + l] >> 2 jq) & 3) - (bit 4 ip + jq of
+      //      hmask[l] ? 0 : 4) (dequantize.cuh:123-152).  The lane reads qs[32 ip + 16 (c & 1) ..] and hmask[16 (c & 1) ..]; operand
+      //      f = 2 ip + m takes jq = 2 m + (c >> 1) out of them: again sub-block 4 f + c in chunk c.
+      //      Every sub-block has its own scale, so a K = 64 MFMA must not mix chunks: M8 splits an operand in two MFMAs (token rows
+      //      0-7 take chunk 0 | 2, rows 8-15 chunk 1 | 3), the 16-token form in four with the other chunks of B zeroed.
+      //      float(C) d8 (d sc) per sub-block (mmq.cuh:1726-1732, :51-72 re-associated). ----
       typedef unsigned v4u_a2 __attribute__((ext_vector_type(4), aligned(2)));
       const uint8_t* blk = wl + L::W + j * SB + s * UB + (k6_last_row ? k6_shift : 0);
-      const float d6 = bits_h_f32(*(const uint16_t*)(blk + off::Q6_K_D));
+      const float d6 = bits_h_f32(*(const uint16_t*)(blk + (F::k6 ? off::Q6_K_D : off::Q3_K_D)));
       const v4i zero = {0, 0, 0, 0};
-      auto sub32 = [](uint32_t x) { return ((x | 0x80808080u) - 0x20202020u) ^ 0x80808080u; };   // per byte x - 32 as int8 (x <= 63)
+      auto sub_off = [](uint32_t x) {   // per byte x - 32 (Q6_K, x <= 63) / x - 4 (Q3_K, x <= 7) as int8
+        constexpr uint32_t o = F::k6 ? 0x20202020u : 0x04040404u;
+        return ((x | 0x80808080u) - o) ^ 0x80808080u;
+      };
+      struct __attribute__((packed, aligned(2))) u32x3_l { uint32_t v[3]; };
+      u32x3_l s3 = {};
+      if constexpr (F::k3) s3 = *(const u32x3_l*)(blk + off::Q3_K_SC);
+      auto sub_scale = [&](int sb) -> float {   // the sub-block's integer scale
+        if constexpr (F::k6) return (float)(int8_t)blk[off::Q6_K_SC + sb];
+        else return (float)q3k_scale(s3.v[0], s3.v[1], s3.v[2], sb);
+      };
 #pragma unroll
       for (int ip = 0; ip < 2; ++ip) {
-        const v4u_a2 ql = *(const v4u_a2*)(blk + off::Q6_K_QL + 64 * ip + 16 * c);
-        const v4u_a2 qh = *(const v4u_a2*)(blk + off::Q6_K_QH + 32 * ip + 16 * (c & 1));
         const int jl = c >> 1;
         v4i B[2];
+        if constexpr (F::k6) {
+          const v4u_a2 ql = *(const v4u_a2*)(blk + off::Q6_K_QL + 64 * ip + 16 * c);
+          const v4u_a2 qh = *(const v4u_a2*)(blk + off::Q6_K_QH + 32 * ip + 16 * (c & 1));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          B[0][i] = (int)sub32((ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * jl)) & 0x03030303u) << 4));
-          B[1][i] = (int)sub32(((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * jl + 4)) & 0x03030303u) << 4));
+          for (int i = 0; i < 4; ++i) {
+            B[0][i] = (int)sub_off((ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * jl)) & 0x03030303u) << 4));
+            B[1][i] = (int)sub_off(((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * jl + 4)) & 0x03030303u) << 4));
+          }
+        } else {
+          const v4u_a2 qs = *(const v4u_a2*)(blk + off::Q3_K_QS + 32 * ip + 16 * (c & 1));
+          const v4u_a2 hm = *(const v4u_a2*)(blk + off::Q3_K_HM + 16 * (c & 1));
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              B[m][i] = (int)sub_off(((qs[i] >> (2 * (2 * m + jl))) & 0x03030303u) | (((hm[i] >> (4 * ip + 2 * m + jl)) & 0x01010101u) << 2));
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -244,7 +270,7 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
             for (int i = 0; i < 4; ++i) { Aa[i] = ka ? A[i] : 0; Ab[i] = kb ? A[i] : 0; }
             const v4i Ca = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aa, B[m], zero, 0, 0, 0);   // lane quad c: sub-block 4 f + (c >> 1)
             const v4i Cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ab, B[m], zero, 0, 0, 0);   //              sub-block 4 f + 2 + (c >> 1)
-            const float dwa = d6 * (float)(int8_t)blk[off::Q6_K_SC + 4 * f + sel], dwb = d6 * (float)(int8_t)blk[off::Q6_K_SC + 4 * f + 2 + sel];
+            const float dwa = d6 * sub_scale(4 * f + sel), dwb = d6 * sub_scale(4 * f + 2 + sel);
             const uint8_t* tq = wl + L::TAB + s * 256 + ip * 128 + (c & 1) * 64;   // [token quad][group of the half][token] fp32 d8
             const v4u_t da = *(const v4u_t*)(tq + (2 * m) * 16), db = *(const v4u_t*)(tq + (2 * m + 1) * 16);
             const uint32_t ta[4] = {da[0], da[1], da[2], da[3]}, tb[4] = {db[0], db[1], db[2], db[3]};
@@ -261,7 +287,7 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
               for (int i = 0; i < 4; ++i) Bm[cc][i] = c == cc ? B[m][i] : 0;
             float dw[4];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) dw[cc] = d6 * (float)(int8_t)blk[off::Q6_K_SC + 4 * f + cc];
+            for (int cc = 0; cc < 4; ++cc) dw[cc] = d6 * sub_scale(4 * f + cc);
 #pragma unroll
             for (int jj = 0; jj < NTT; ++jj) {
               const uint8_t* tq = wl + L::TAB + (jj * ((MAXU + 1) / 2) * 2 + s) * 512 + ip * 256 + c * 64;
@@ -647,7 +673,7 @@ static int launch_t16_dt(const void* w, const void* q8, void* y, int64_t batch, 
   if (batch <= 16) return launch_t16<T, DT, false, 1>(w, q8, y, batch, k, n, ldy, s, ep);
   // two token tiles per wave: the K-quants only (the 32-element-block instances spill 70 - 90 registers; ggq_mmq_t16_supported
   // keeps their batches at 16)
-  if constexpr (T16Fmt<T>::legacy || T16Fmt<T>::k6) return GGQ_ERR_SHAPE;
+  if constexpr (T16Fmt<T>::legacy || T16Fmt<T>::sub16) return GGQ_ERR_SHAPE;
   else return launch_t16<T, DT, false, 2>(w, q8, y, batch, k, n, ldy, s, ep);
 }
 
@@ -675,7 +701,7 @@ extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type
   if (n_rows == 0 || batch == 0) return GGQ_OK;
   if (!ggq_mmq_t16_supported(type, k, batch)) return ggq_mmq_t16_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
   if (n_rows > 0x7fffffffLL - 64) return GGQ_ERR_SHAPE;
-  if (type == GGQ_TYPE_Q6_K && (n_rows * ggq_row_bytes(type, k) < 1024 || n_rows * ggq_row_bytes(type, k) >= (1ll << 32)))
+  if ((type == GGQ_TYPE_Q6_K || type == GGQ_TYPE_Q3_K) && (n_rows * ggq_row_bytes(type, k) < 1024 || n_rows * ggq_row_bytes(type, k) >= (1ll << 32)))
     return GGQ_ERR_SHAPE;   // the shifted copy of the last row starts inside the tensor; 32-bit offsets into the whole tensor
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
@@ -690,6 +716,7 @@ extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type
     case GGQ_TYPE_Q5_0: return launch_t16_t<GGQ_TYPE_Q5_0>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     case GGQ_TYPE_Q5_1: return launch_t16_t<GGQ_TYPE_Q5_1>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     case GGQ_TYPE_Q6_K: return launch_t16_t<GGQ_TYPE_Q6_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
+    case GGQ_TYPE_Q3_K: return launch_t16_t<GGQ_TYPE_Q3_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);
     default: return GGQ_ERR_TYPE;
   }
 }

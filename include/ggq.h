@@ -184,7 +184,7 @@ int ggq_mul_mat_q_epi(const void* w, const void* x, void* y, int type, int dtype
  * half2(d, sum) | float d  ds[2 halves][4 token quads][4 groups][4 tokens] } in the element order the weight format's
  * MFMA operand needs (one operand fragment = 1 KB contiguous).  q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte
  * aligned.  ggq_mul_mat_q_t16 takes the epilogue arguments of ggq_mul_mat_q_pretiled_epi.
- * Formats: Q4_K Q5_K (batch <= 32) and Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q6_K (batch <= 16; Q6_K tensors of 1 KB .. 4 GiB); k a multiple of 256
+ * Formats: Q4_K Q5_K (batch <= 32) and Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q6_K Q3_K (batch <= 16; Q6_K / Q3_K tensors of 1 KB .. 4 GiB); k a multiple of 256
  * (ggq_mmq_t16_supported; GGQ_ERR_SHAPE otherwise).  Batches of at most 8 use the 8-token form of the tile (2304 bytes). */
 int ggq_mmq_t16_type_supported(int type);
 int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch);

@@ -59,7 +59,7 @@ def test_mmq_routing_table():
     from ggq import lib as ggqlib
     L = ggqlib.cpu()
     NONE, DOT4, LDS_TILE, STREAM, T16 = range(5)
-    Q4_K, Q5_K, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q6_K = 12, 13, 2, 3, 6, 7, 8, 14
+    Q4_K, Q5_K, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q6_K, Q3_K = 12, 13, 2, 3, 6, 7, 8, 14, 11
     shapes = [(4096, 11008), (11008, 4096), (8192, 3584), (8192, 28672), (256, 16), (4096 + 32, 64)]
     for k, n in shapes:
         for t in WEIGHT_TYPES:
@@ -91,13 +91,13 @@ def test_mmq_routing_table():
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
         many = n >= 8192
-        for t32, frm in ((Q4_0, 5), (Q4_1, 5), (Q8_0, 5), (Q5_0, 9), (Q5_1, 17)):
+        for t32, frm in ((Q4_0, 5), (Q4_1, 5), (Q8_0, 5), (Q5_0, 9), (Q5_1, 17), (Q3_K, 17)):
             for b in (2, 4, 5, 8, 9, 16):
                 want_t16 = b >= (frm if many else 2)
                 r = L.ggq_mmq_route(t32, b, k, n)
                 assert (r == T16) == want_t16, (t32, b, k, n, r)
                 if not want_t16:
-                    assert r == (DOT4 if b <= 8 else (LDS_TILE if t32 == Q8_0 else STREAM))
+                    assert r == (DOT4 if b <= (4 if t32 == Q3_K else 8) else (LDS_TILE if t32 == Q8_0 else STREAM))
             assert L.ggq_mmq_route(t32, 17, k, n) != T16
     # invalid inputs
     assert L.ggq_mmq_route(1, 8, 4096, 64) == NONE and L.ggq_mmq_route(Q4_K, 0, 4096, 64) == NONE

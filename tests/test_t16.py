@@ -40,7 +40,7 @@ def test_quantize_q8_1_t16_bit_exact(oracle, dtype, t, batch, k):
 def test_mmq_t16_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     """ragged row tiles and token tiles, 1 .. 12 K-slices of equal and unequal length, slices of several LDS rounds (K > 12288)"""
     from ggq.formats import BLOCK
-    if (BLOCK[t][0] == 32 or t == GGMLType.Q6_K) and batch > 16:   # the 32-element-block formats and Q6_K have no two-token-tile instance
+    if (BLOCK[t][0] == 32 or t in (GGMLType.Q6_K, GGMLType.Q3_K)) and batch > 16:   # the 32-element-block formats and Q6_K have no two-token-tile instance
         assert ggqlib.hip().ggq_mmq_t16_supported(int(t), k, batch) == 0
         q = torch.zeros(int(ggqlib.hip().ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
         assert ggqlib.hip().ggq_mul_mat_q_t16(util.vp(q), util.vp(q), util.vp(q), int(t), 1, batch, k, n_rows, n_rows, 0, None, util.stream_ptr()) == -2
@@ -123,7 +123,7 @@ def test_mmq_t16_full_size_properties(oracle, t, n_rows, k, batch):
     properties on every output — bit-reproducible run to run, weight-row permutation, token permutation, exact scaling of
     X by a power of two (fp32 in / out)."""
     from ggq.formats import BLOCK
-    if (BLOCK[t][0] == 32 or t == GGMLType.Q6_K) and batch > 16:
+    if (BLOCK[t][0] == 32 or t in (GGMLType.Q6_K, GGMLType.Q3_K)) and batch > 16:
         batch = 16
     w = synth.random_weight(t, n_rows, k, seed=21)
     wd = util.dev_bytes(w)

@@ -163,6 +163,10 @@ def t16_perm(t):
                 perm.append((e0 // 8, e0 // 8 + 1))
             elif t == GGMLType.Q8_0:                  # the lane's 16 bytes are 16 consecutive elements
                 perm.append((2 * (4 * f + c), 2 * (4 * f + c) + 1))
+            elif t == GGMLType.Q3_K:                  # element 128 ip + 32 jq + l <- bits 2 jq of qs[32 ip + l]: operand f = 2 ip + m, lane chunk c
+                ip, m = divmod(f, 2)                  # reads qs[32 ip + 16 (c & 1) ..] and takes jq = 2 m + (c >> 1)
+                e0 = 128 * ip + 32 * (2 * m + (c >> 1)) + 16 * (c & 1)
+                perm.append((e0 // 8, e0 // 8 + 1))
             elif t == GGMLType.Q6_K:                  # element 128 ip + 32 jq + l <- nibble (jq >> 1) of ql[64 ip + 32 (jq & 1) + l]:
                 ip, hi = divmod(f, 2)                 # operand f = 2 ip + hi, lane chunk c reads ql[64 ip + 16 c ..]: jq & 1 = c >> 1,
                 jq, l0 = 2 * hi + (c >> 1), 16 * (c & 1)   # l = 16 (c & 1) .., and the nibble chosen gives jq >> 1 = hi
