@@ -663,6 +663,18 @@ def secondary_configs(L, dev, w_q4k, w_q4k_ring, x128, scratch, args):
     rec("mmq_Q8_0_batch16",
         lambda b: L.ggq_mul_mat_q(vp(b[0]), vp(x16), vp(y128), Q8_0, 1, 16, K_DIM, N_DIM, vp(scratch), cur_stream()),
         [rings[Q8_0]], algo_bytes_matmul(Q8_0, N_DIM, K_DIM, 16), 2.0 * 16 * N_DIM * K_DIM, iters=52)
+    rec("mmq_Q6_K_batch8",
+        lambda b: L.ggq_mul_mat_q(vp(b[0]), vp(x8), vp(y128), Q6_K, 1, 8, K_DIM, N_DIM, vp(scratch), cur_stream()),
+        [rings[Q6_K]], algo_bytes_matmul(Q6_K, N_DIM, K_DIM, 8), 2.0 * 8 * N_DIM * K_DIM, iters=52)
+    # the grid-codebook IQ formats through the GEMV (codebook staged in LDS)
+    IQ3_S, IQ2_XXS = 21, 16
+    for t, nm in ((IQ3_S, "IQ3_S"), (IQ2_XXS, "IQ2_XXS")):
+        wi = torch.from_numpy(synth.random_weight(t, N_DIM, K_DIM, seed=5)).to(dev)
+        ri = ring_of(wi, wi.numel())
+        rec(f"mmvq_{nm}_batch1",
+            lambda b, t=t: L.ggq_mul_mat_vec_q(vp(b[0]), vp(x1), vp(y1), t, 1, K_DIM, N_DIM, vp(sc1), cur_stream()),
+            [ri], algo_bytes_matmul(t, N_DIM, K_DIM, 1), 2.0 * N_DIM * K_DIM, iters=104)
+        del ri, wi
     # north_star: Q8_0 at batch 1 too (MMVQ)
     rec("mmvq_Q8_0_batch1",
         lambda b: L.ggq_mul_mat_vec_q(vp(b[0]), vp(x1), vp(y1), Q8_0, 1, K_DIM, N_DIM, vp(sc1), cur_stream()),
