@@ -150,8 +150,8 @@ int ggq_mul_mat_q_prequant(const void* w, const void* q, void* y, int type, int 
 /* Fragment-major variant of the MMQ activation scratch (same 144 bytes per 128 elements and token,
  * same values as ggq_quantize_q8_1_mmq, regrouped per (k/128, token/32) into 4608-byte tiles
  * { int8 qs[4 groups][2 K-halves][32 tokens][16]; ds[2 group pairs][32 tokens][2] } so that one MFMA
- * operand fragment is 1 KB contiguous).  This is what ggq_mul_mat_q uses internally from batch 5 (9 for
- * Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q4_K, 33 for Q6_K, 65 for Q8_0) for every (type, k) ggq_mmq_tiled_supported() reports: all ten formats, k a whole
+ * operand fragment is 1 KB contiguous).  This is what ggq_mul_mat_q uses internally for the batches ggq_mmq_route() reports as
+ * GGQ_MMQ_ROUTE_STREAM (the large ones), for every (type, k) ggq_mmq_tiled_supported() reports: all ten formats, k a whole
  * number of blocks, rows of at most 32 MiB; exported so a caller can quantise once for several weight
  * matrices (the reference quantises per call, HK/ggml/mmq.cu:208-230).
  * q: >= ggq_mmq_scratch_bytes(batch,k) bytes, 16-byte aligned.  w: 2-byte aligned as everywhere
