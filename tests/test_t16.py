@@ -116,6 +116,24 @@ def test_mmq_t16_ldy_epilogues_unaligned_and_errors(oracle):
 
 
 @pytest.mark.parametrize("t", T16_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("batch", [3, 12])
+def test_mmq_t16_weights_at_any_2_byte_alignment(oracle, t, batch):
+    """the ABI asks for 2-byte aligned weights: the LDS-DMA image (global_load_lds / buffer_load ... lds) and the unaligned LDS
+    reads of the 18 .. 34-byte blocks and of Q6_K / Q3_K must give the same bits wherever the tensor starts"""
+    k, n_rows = 1280, 37
+    w = synth.random_weight(t, n_rows, k, seed=6)
+    x = _x((batch, k), torch.float16, seed=16)
+    y = util.gpu_mmq_t16(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, torch.float16, f"t16 {t.name}")
+    for shift in (2, 6, 14):
+        buf = torch.zeros(w.size + 64, dtype=torch.uint8, device="cuda")
+        off = (-buf.data_ptr()) % 16 + shift
+        buf[off:off + w.size] = torch.from_numpy(w.reshape(-1)).cuda()
+        assert torch.equal(util.gpu_mmq_t16(w, x, t, n_rows, w_dev=buf[off:off + w.size]), y), (t.name, shift)
+
+
+@pytest.mark.parametrize("t", T16_TYPES, ids=lambda t: t.name)
 @pytest.mark.parametrize("n_rows,k", [(11008, 4096), (4096, 11008), (3584, 8192)])
 @pytest.mark.parametrize("batch", [8, 32])
 def test_mmq_t16_full_size_properties(oracle, t, n_rows, k, batch):
