@@ -116,6 +116,26 @@ def test_mmq_t16_ldy_epilogues_unaligned_and_errors(oracle):
 
 
 @pytest.mark.parametrize("t", T16_TYPES, ids=lambda t: t.name)
+def test_mmq_t16_random_shapes(oracle, t):
+    """seeded sweep over ragged shapes: every combination of short / long K (one to several LDS rounds per wave), partial last
+    row tile, partial token tile and both tile forms, against the oracle"""
+    from ggq.formats import BLOCK
+    rng = np.random.default_rng(1000 + int(t))
+    bmax = 32 if t in (GGMLType.Q4_K, GGMLType.Q5_K) else 16
+    for case in range(14):
+        batch = int(rng.integers(1, bmax + 1))
+        k = 256 * int(rng.choice([1, 2, 3, 5, 7, 12, 17, 24, 41, 64]))
+        n_rows = int(rng.integers(5, 75))   # Q6_K / Q3_K need a tensor of at least 1 KB: 5 rows x 110 bytes x (k / 256) >= 1 KB from k = 512
+        if t in (GGMLType.Q6_K, GGMLType.Q3_K) and n_rows * (k // 256) * BLOCK[t][1] < 1024:
+            n_rows = 12
+        w = synth.random_weight(t, n_rows, k, seed=case)
+        x = _x((batch, k), torch.float32, seed=100 + case)
+        y = util.gpu_mmq_t16(w, x, t, n_rows)
+        ref, yabs = oracle.mul_mat_q(w, x.cpu().numpy(), t, n_rows)
+        util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"t16 random {t.name} b={batch} k={k} n={n_rows}")
+
+
+@pytest.mark.parametrize("t", T16_TYPES, ids=lambda t: t.name)
 @pytest.mark.parametrize("batch", [3, 12])
 def test_mmq_t16_weights_at_any_2_byte_alignment(oracle, t, batch):
     """the ABI asks for 2-byte aligned weights: the LDS-DMA image (global_load_lds / buffer_load ... lds) and the unaligned LDS
