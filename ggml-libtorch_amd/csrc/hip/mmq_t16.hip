@@ -90,7 +90,11 @@ template <int T> struct T16Fmt {
 
 // wave-private LDS (bytes): W [16 rows][MAXU units] raw bytes | TAB scale tables
 template <int T, bool M8, int NTT, int MAXU> struct T16Lds {
-  static constexpr int SB = (MAXU * T16Fmt<T>::UB + 15) / 16 * 16;   // LDS pitch of one row's slice (whole 16-byte DMA chunks)
+  // LDS pitch of one row's slice: whole 16-byte DMA chunks.  For the 32-element-block formats an ODD number of them (one pad chunk
+  // that repeats valid bytes): the 16 lanes of a K-chunk read at this pitch, which covers the 64 banks exactly once only then
+  // (Q4_0 batch 16 12.2 -> 11.0 us, Q8_0 12.3 -> 11.6; for the K-quants the same pad measured 0 .. +7 %: not applied).
+  static constexpr int SB0 = (MAXU * T16Fmt<T>::UB + 15) / 16 * 16;
+  static constexpr int SB = (T16Fmt<T>::legacy && (SB0 / 16) % 2 == 0) ? SB0 + 16 : SB0;
   static constexpr int NI = (16 * SB + 1023) / 1024;       // DMA instructions (1 KB each) of the weight image (the last may be partial:
                                                            // its surplus lanes repeat the final chunk into the padding)
   static constexpr int TT = M8 ? 256 : 512;                // scale table of one (unit, token tile)
