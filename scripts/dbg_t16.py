@@ -1,3 +1,5 @@
+"""Which (token, row) entries of the 16-token-tile kernel disagree with the oracle, and by what factor — the first thing to look at
+when a new format's operand mapping is off.  usage: python scripts/dbg_t16.py type batch k n_rows"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ggml-libtorch_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
