@@ -429,6 +429,7 @@ def main():
             dist.barrier()
 
     value_warm = None
+    gpu_side = [None]
     if world == 1:
         y = torch.empty((BATCH, N_DIM), dtype=torch.float16, device=dev)
 
@@ -453,10 +454,12 @@ def main():
                     print(f"[bench] graph capture failed ({e}); timing eager launches", file=sys.stderr)
                     graph = None
                     torch.cuda.synchronize()
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=True)
+            began = torch.cuda.Event(enable_timing=True)
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            began.record()
             if graph is not None:
                 graph.replay()
             else:
@@ -469,8 +472,11 @@ def main():
                 pass
             torch.cuda.synchronize()
             barrier()
-            return time.perf_counter() - t0, graph is not None
+            wall = time.perf_counter() - t0
+            gpu_side[0] = began.elapsed_time(done) * 1e-3   # the same steps by HIP events: what the host bracket adds is launch + wake-up
+            return wall, graph is not None
 
+        gpu_side = [None]
         elapsed_warm, _ = timed([w])          # untimed for the headline: the warm twin, reported beside it
         value_warm = bytes_per_step * args.steps / elapsed_warm / 1e9
         elapsed, graphed = timed(w_ring)      # the headline: EXACTLY args.steps steps, weights streamed from HBM
@@ -539,6 +545,11 @@ def main():
                                   f"({len(w_ring) * w.numel() >> 20} MiB > 256 MiB Infinity Cache + 32 MiB L2)"},
         "pct_hbm_roofline": round(100.0 * value / world / HBM_PEAK_GBS, 2),
     }
+    if world == 1 and gpu_side[0]:
+        # the same K steps timed by HIP events on the stream: the host bracket above (which `value` uses) additionally contains one
+        # graph launch and the host's wake-up, a fixed cost that weighs 5 - 9 % at --steps 20 and < 1 % at --steps 200
+        out["ms_per_step_gpu_events"] = round(gpu_side[0] * 1e3 / args.steps, 6)
+        out["value_gpu_events"] = round(bytes_per_step * args.steps / gpu_side[0] / 1e9, 2)
     if value_warm is not None:
         out["value_warm"] = round(value_warm, 2)
         out["config"]["cache_state_value_warm"] = "warm: every step re-reads ONE 25 MB weight tensor (resident in L2 + Infinity Cache)"
