@@ -37,6 +37,10 @@
 #define GGQ_DEQUANT_CH(T) 3
 #endif
 
+#ifndef GGQ_DEQUANT_LDS_GRID
+#define GGQ_DEQUANT_LDS_GRID 1
+#endif
+
 namespace ggq {
 
 __device__ __forceinline__ _Float16 i2h(int v) { return (_Float16)v; }  // __int2half_rn
@@ -287,10 +291,11 @@ template <> struct Decode<GGQ_TYPE_IQ4_XS> {
 // d = half2float(x.d) * (0.5f + scale) * 0.25f | 0.5f evaluated left to right, ONE rounding to fp16.  (Multiplying by
 // +-1 commutes with the rounding: the product with the signed grid value is the same number, zero signs included.)
 template <int T> struct IqDecode {
-  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) { run_g(IqGrid<T>::table(), b, sub, y); }
+  static __device__ __forceinline__ void run_g(const void* grid, const uint8_t* b, int sub, _Float16* y) {   // grid: the codebook (global or an LDS copy)
     uint32_t lo, hi;
     float mul;
-    IqRun<T>::get(IqGrid<T>::table(), b, sub >> 2, sub & 3, lo, hi, mul);
+    IqRun<T>::get(grid, b, sub >> 2, sub & 3, lo, hi, mul);
     const float d = bits_h_f32(ld_u16(b)) * mul * IqRun<T>::post;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -319,23 +324,25 @@ __device__ __forceinline__ void iq1_emit(uint32_t lo, uint32_t hi, float d, floa
   }
 }
 template <> struct Decode<GGQ_TYPE_IQ1_S> {
-  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) { run_g(ggq_iq1s_grid_gpu, b, sub, y); }
+  static __device__ __forceinline__ void run_g(const void* grid, const uint8_t* b, int sub, _Float16* y) {
     const int ib = sub >> 2, il = sub & 3;
     const uint32_t qh = ld_u16(b + off::IQ1_S_QH + 2 * ib);
     uint32_t lo, hi;
-    iq1_grid(ggq_iq1s_grid_gpu, b[off::IQ1_S_QS + 4 * ib + il] | (((qh >> (3 * il)) & 7) << 8), lo, hi);
+    iq1_grid(grid, b[off::IQ1_S_QS + 4 * ib + il] | (((qh >> (3 * il)) & 7) << 8), lo, hi);
     const float delta = (qh & 0x8000) ? -1.0f - IQ1_DELTA : -1.0f + IQ1_DELTA;
     iq1_emit(lo, hi, bits_h_f32(ld_u16(b + off::IQ1_S_D)) * (float)(2 * ((qh >> 12) & 7) + 1), delta, y);
   }
 };
 template <> struct Decode<GGQ_TYPE_IQ1_M> {
-  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) {
+  static __device__ __forceinline__ void run(const uint8_t* b, int sub, _Float16* y) { run_g(ggq_iq1s_grid_gpu, b, sub, y); }
+  static __device__ __forceinline__ void run_g(const void* grid, const uint8_t* b, int sub, _Float16* y) {
     const int ib = sub >> 2, il = sub & 3;
     const int ib16 = 2 * ib + (il >> 1);
     const uint32_t sc = ld_u16(b + off::IQ1_M_SC + 2 * (ib16 >> 2));
     const uint32_t qh = b[off::IQ1_M_QH + ib16] >> (4 * (il & 1));
     uint32_t lo, hi;
-    iq1_grid(ggq_iq1s_grid_gpu, b[off::IQ1_M_QS + 4 * ib + il] | ((qh & 7) << 8), lo, hi);
+    iq1_grid(grid, b[off::IQ1_M_QS + 4 * ib + il] | ((qh & 7) << 8), lo, hi);
     const float delta = (qh & 0x08) ? -1.0f - IQ1_DELTA : -1.0f + IQ1_DELTA;
     iq1_emit(lo, hi, iq1m_super_scale(b) * (float)(2 * ((sc >> (3 * (ib16 & 3))) & 7) + 1), delta, y);
   }
@@ -348,13 +355,23 @@ __global__ void __launch_bounds__(256) dequant_kernel(const uint8_t* __restrict_
                                                       int64_t n_chunks) {
   constexpr int CPB = Fmt<T>::QK / 8;  // 8-element chunks per block
   const int64_t c0 = (int64_t)blockIdx.x * (256 * CH) + threadIdx.x;
+  // the grid-codebook IQ formats: the codebook (1 - 8 KB) is staged in LDS — a per-lane lookup in global memory touches up to 64
+  // cache lines per wave-level load, in LDS it is one ds_read (GGQ_DEQUANT_LDS_GRID = 0: ablation)
+  constexpr int GB = GGQ_DEQUANT_LDS_GRID ? IqGrid<T>::BYTES : 0;
+  __shared__ __attribute__((aligned(16))) uint8_t lgrid[GB ? GB : 16];
+  if constexpr (GB != 0) {
+    const v4i* gg = (const v4i*)IqGrid<T>::table();
+    for (int i = threadIdx.x; i < GB / 16; i += 256) ((v4i*)lgrid)[i] = gg[i];
+    __syncthreads();
+  }
   h8 v[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int64_t c = min(c0 + i * 256, n_chunks - 1);   // clamped, never predicated: the loads of all chunks go out first
     const int64_t ib = c / CPB;
     _Float16 y[8];
-    Decode<T>::run(w + ib * Fmt<T>::BS, (int)(c - ib * CPB), y);
+    if constexpr (GB != 0) Decode<T>::run_g(lgrid, w + ib * Fmt<T>::BS, (int)(c - ib * CPB), y);
+    else Decode<T>::run(w + ib * Fmt<T>::BS, (int)(c - ib * CPB), y);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[i][e] = y[e];
   }
