@@ -153,6 +153,9 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
     case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q3_K: t16_to = n_rows < 8192 ? 16 : 0; break;
     default: break;
   }
+  // one token through this entry point: with few rows the 16-token tiles beat the dot4 kernel there too (Q4_K 4096 x 11008 10.7 / 12.4 us
+  // against 10.1 / 11.1 at batch 2; 3584 x 8192 9.3 / 10.0 against 8.5 / 9.1), with many they do not (11008 x 4096: 8.5 against 9.8)
+  if (t16_to > 0 && t16_from == 2 && n_rows < 8192) t16_from = 1;
   const bool t16_shape_ok = (type != GGQ_TYPE_Q6_K && type != GGQ_TYPE_Q3_K) || (n_rows * ggq_row_bytes(type, k) >= 1024 && n_rows * ggq_row_bytes(type, k) < (1ll << 32));   // ggq_mul_mat_q_t16's own guards
   if (t16_shape_ok && ggq_mmq_t16_supported(type, k, batch) && batch >= t16_from && batch <= t16_to) return GGQ_MMQ_ROUTE_T16;
   // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):

@@ -8,7 +8,7 @@ from ggq import lib as ggqlib, synth
 t = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 11008
 batches = [int(a) for a in sys.argv[3:]] or [1, 2, 4, 5, 8, 16, 32]
-K = 4096
+K = int(os.environ.get("K", 4096))
 L = ggqlib.hip() if not os.environ.get("GGQ_LIB") else ggqlib._bind(ctypes.CDLL(os.environ["GGQ_LIB"]), ggqlib.HIP_SYMBOLS)
 vp = lambda x: ctypes.c_void_p(x.data_ptr()); st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 w0 = torch.from_numpy(synth.random_weight(t, N, K, seed=0)).cuda()
@@ -16,7 +16,7 @@ ws = [w0] + [w0.clone() for _ in range(15)]
 for b in batches:
     x = torch.randn((b, K), generator=torch.Generator().manual_seed(0)).half().cuda()
     y = torch.empty((b, N), dtype=torch.float16, device="cuda")
-    scr = torch.empty(max(int(L.ggq_mmq_scratch_bytes(b, K)), int(L.ggq_mmvq_scratch_bytes(K))) + 4096, dtype=torch.uint8, device="cuda")
+    scr = (torch.zeros if os.environ.get("ZERO_SCRATCH") == "1" else torch.empty)(max(int(L.ggq_mmq_scratch_bytes(b, K)), int(L.ggq_mmvq_scratch_bytes(K))) + 4096, dtype=torch.uint8, device="cuda")
     def f(i):
         w = ws[i % len(ws)]
         if b == 1: return L.ggq_mul_mat_vec_q(vp(w), vp(x), vp(y), t, 1, K, N, vp(scr), st())

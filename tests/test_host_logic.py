@@ -71,7 +71,7 @@ def test_mmq_routing_table():
                     continue
                 assert r in (DOT4, LDS_TILE, STREAM, T16)
                 if r == T16:
-                    assert k % 256 == 0 and 2 <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
+                    assert k % 256 == 0 and (1 if n < 8192 else 2) <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
                 if r == DOT4:
                     assert b <= 8
                 prev = r
@@ -82,12 +82,12 @@ def test_mmq_routing_table():
         for b in (2, 8, 16):
             assert L.ggq_mmq_route(Q5_K, b, k, n) == T16
         assert L.ggq_mmq_route(Q5_K, 32, k, n) == STREAM
-        assert L.ggq_mmq_route(Q4_K, 1, k, n) == DOT4 and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
+        assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16) and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == STREAM
         assert L.ggq_mmq_route(Q8_0, 17, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 64, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
-        assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == DOT4
+        assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8, 16)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
-        assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == DOT4
+        assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == (DOT4 if n >= 8192 else T16)
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
         many = n >= 8192
