@@ -325,13 +325,12 @@ def strong_scaling_config5(L, dev, world, rank, dist):
                 pg = PeerSlabGather(b, N5, torch.float16, dev)
 
                 def peer_step():
-                    out = pg.local
                     if b == 1:
-                        rc = L.ggq_mul_mat_vec_q(vp(w5), vp(x), vp(out), Q4_K, 1, K5, rows, vp(sc), cur_stream())
-                    else:
-                        rc = L.ggq_mul_mat_q_ld(vp(w5), vp(x), vp(out), Q4_K, 1, b, K5, rows, rows, vp(sc), cur_stream())
-                    assert rc == 0, rc
-                    pg.gather()
+                        rc = L.ggq_mul_mat_vec_q(vp(w5), vp(x), vp(pg.local), Q4_K, 1, K5, rows, vp(sc), cur_stream())
+                        assert rc == 0, rc
+                        pg.gather()
+                    else:   # the GEMM's own stores to every rank's slot + flags from its last workgroup where the 16-token tiles
+                        pg.matmul_gather(x, w5, Q4_K, sc)   # serve the batch (8); ggq_mul_mat_q_ld + scatter kernel otherwise (128)
                 for _ in range(3):
                     peer_step()
                 torch.cuda.synchronize()

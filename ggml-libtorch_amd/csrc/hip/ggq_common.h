@@ -183,6 +183,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     if (e_ != hipSuccess) return GGQ_ERR_LAUNCH;        \
   } while (0)
 
+// Multi-destination write-back of a GEMM (ggq_mul_mat_q_gather): the output slab goes to dst[0 .. n_dst) — the caller's own slot
+// first, then the same slot of every peer's gather buffer (mapped with ggq_peer_import) — and, once every workgroup of the launch
+// has released its stores at system scope, `generation` is written into flag[0 .. n_flag).  n_dst = 0: a plain launch.
+struct GatherOut {
+  void* dst[8];
+  uint32_t* flag[8];
+  uint32_t* arrivals;    // zero-initialised 4-byte word of the caller's memory; the kernel leaves it zero
+  uint32_t generation;
+  int n_dst, n_flag;
+};
+
 // Experiment knobs (environment variables that force a kernel variant) exist only in -DGGQ_TUNING builds
 // (scripts/build_variant.sh); the shipped library takes no decision from the environment.
 #ifdef GGQ_TUNING

@@ -55,7 +55,7 @@ namespace ggq {
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
-struct Epi16 { int kind; const void* aux; };
+struct Epi16 { int kind; const void* aux; GatherOut go; };
 template <int DT>
 __device__ __forceinline__ float t16_epilogue(float v, int epi, const void* aux, int64_t yi, int row) {
   if (epi == GGQ_EPI_BIAS) return v + Elem<DT>::ld(aux, row);
@@ -112,7 +112,7 @@ typedef __attribute__((address_space(3))) void* t16_lptr;
 template <int T, int DT, bool M8, int NTT, int MAXU, int MAXKS>
 __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
                                                              void* __restrict__ y, int n_units, int ups, int n_rows, int batch,
-                                                             int64_t ldy, int n_tt, int epi, const void* __restrict__ aux) {
+                                                             int64_t ldy, int n_tt, int epi, const void* __restrict__ aux, GatherOut go) {
   using F = T16Fmt<T>;
   using L = T16Lds<T, M8, NTT, MAXU>;
   static_assert(!M8 || NTT == 1, "M8: one token tile");
@@ -572,6 +572,7 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the last (unused) fragment prefetch
   __syncthreads();
   float* red = (float*)lds;   // [K-slice][NTT][4][64]
+  void* otile = lds + KS * NTT * 1024;   // behind the partial sums: the output tile for the wide stores to peers (<= 2 KB)
 #pragma unroll
   for (int jj = 0; jj < NTT; ++jj)
 #pragma unroll
@@ -595,10 +596,58 @@ __global__ void __launch_bounds__(64 * MAXKS) mmq_t16_kernel(const uint8_t* __re
     }
     if (t < batch && row < n_rows) {
       const int64_t yi = (int64_t)t * ldy + row;
-      Elem<DT>::st(y, yi, t16_epilogue<DT>(v, epi, aux, yi, row));
+      const float o = t16_epilogue<DT>(v, epi, aux, yi, row);
+      Elem<DT>::st(y, yi, o);
+      // peers (go.n_dst > 1): the tile is staged in LDS [token of the tile][16 rows] and leaves in 16-byte stores below — a
+      // peer's buffer is uncached memory behind xGMI, where 64 separate 2-byte stores per wave cost 4 x the whole kernel
+      if (go.n_dst > 1) Elem<DT>::st(otile, (M8 ? 4 * c + r : 16 * jj + 4 * c + r) * 16 + j, o);
     }
   }
   T16_STAMP(6);
+  if (go.n_dst > 1) {   // (kernel-uniform)
+    __syncthreads();
+    constexpr int ESZ = (int)sizeof(typename Elem<DT>::type), RPC = 16 / ESZ, CPT = 16 / RPC;   // rows per 16-byte chunk, chunks per token
+    const int n_tok = M8 ? 8 : 16 * NTT;
+    for (int idx = threadIdx.x; idx < n_tok * CPT; idx += blockDim.x) {
+      const int tl = idx / CPT, h = idx - tl * CPT;
+      const int t = (M8 ? 0 : 16 * tt0) + tl, r0 = n0 + h * RPC;
+      if (t >= batch || r0 >= n_rows) continue;
+      const int64_t e0 = (int64_t)t * ldy + r0;
+      if (r0 + RPC <= n_rows) {
+        const v4i v16 = *(const v4i*)((const uint8_t*)otile + (tl * 16 + h * RPC) * ESZ);
+        for (int d = 1; d < go.n_dst; ++d) {   // system-coherent write-through store: visible to the peer without a cache write-back
+          uint8_t* p = (uint8_t*)go.dst[d] + e0 * ESZ;
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v16) : "memory");
+        }
+      } else {   // a row tile cut by the end of the matrix: element by element
+        for (int e = 0; r0 + e < n_rows; ++e) {
+          const float o = Elem<DT>::ld(otile, tl * 16 + h * RPC + e);
+          for (int d = 1; d < go.n_dst; ++d) {
+            if constexpr (ESZ == 4) __hip_atomic_store((uint32_t*)go.dst[d] + e0 + e, __builtin_bit_cast(uint32_t, o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else {
+              uint16_t bits;
+              Elem<DT>::st(&bits, 0, o);
+              __hip_atomic_store((uint16_t*)go.dst[d] + e0 + e, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (go.n_flag > 0) {   // (kernel-uniform) publish.  Unlike peer_scatter_kernel (64 workgroups, a system-scope release fence each)
+    // the ~700 workgroups of a GEMM cannot each write back their XCD's L2 (measured: 170 instead of 40 us): the peer stores above are
+    // system-coherent write-through stores, complete when vmcnt reaches zero, so arriving needs no fence; the last workgroup's flag
+    // stores carry the one release.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t before = __hip_atomic_fetch_add(go.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == gridDim.x * gridDim.y - 1) {        // last workgroup: every workgroup's release precedes its arrival
+        __hip_atomic_store(go.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int d = 0; d < go.n_flag; ++d) __hip_atomic_store(go.flag[d], go.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 template <int T, int DT, bool M8, int NTT, int MAXU>
@@ -625,7 +674,7 @@ static int launch_t16_u(const void* w, const void* q8, void* y, int64_t batch, i
     return GGQ_ERR_LAUNCH;
   GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3((unsigned)(64 * ks)), lds, s, (const uint8_t*)w, (const uint8_t*)q8, y,
-                     (int)n_units, (int)ups, (int)n, (int)batch, ldy, (int)n_tt, ep.kind, ep.aux);
+                     (int)n_units, (int)ups, (int)n, (int)batch, ldy, (int)n_tt, ep.kind, ep.aux, ep.go);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }
@@ -694,8 +743,52 @@ static int launch_t16_t(const void* w, const void* q8, void* y, int dt, int64_t 
 
 }  // namespace ggq
 
+namespace ggq {
+int mul_mat_q_t16_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
+                       int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream, const void* go);
+}
 extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
                                  int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream) {
+  return ggq::mul_mat_q_t16_impl(w, q, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream, nullptr);
+}
+
+// The 16-token-tile GEMM with the multi-destination write-back (GatherOut): quantise + kernel, for the (type, batch, shape) that
+// ggq_mmq_route sends to this kernel; GGQ_ERR_SHAPE otherwise (the caller then runs ggq_mul_mat_q_ld + ggq_peer_scatter).
+extern "C" int ggq_mul_mat_q_gather(const void* w, const void* x, void* const* dsts, int n_dst, void* const* flags, int n_flag,
+                                    uint32_t generation, void* arrivals, int type, int dtype, int64_t batch, int64_t k,
+                                    int64_t n_rows, int64_t ldy, void* scratch, void* stream) {
+  using namespace ggq;
+  if (n_dst < 1 || n_dst > 8 || n_flag < 0 || n_flag > 8 || !dsts || (n_flag && (!flags || !arrivals))) return GGQ_ERR_ARG;
+  if (batch < 0 || k <= 0 || n_rows < 0) return GGQ_ERR_ARG;
+  if (batch == 0 || n_rows == 0) return GGQ_ERR_SHAPE;   // nothing would publish the flags
+  if (ggq_mmq_route(type, batch, k, n_rows) != GGQ_MMQ_ROUTE_T16) return ggq_mmq_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
+  GatherOut go{};
+  for (int d = 0; d < n_dst; ++d) {
+    if (!dsts[d]) return GGQ_ERR_ARG;
+    go.dst[d] = dsts[d];
+  }
+  for (int d = 0; d < n_flag; ++d) {
+    if (!flags[d] || ((uintptr_t)flags[d] & 3)) return GGQ_ERR_ARG;
+    go.flag[d] = (uint32_t*)flags[d];
+  }
+  {   // 16-byte stores into the peers' slots: row pitch and bases at 16-byte multiples
+    const int64_t esz = dtype == GGQ_F32 ? 4 : 2;
+    if ((ldy * esz) % 16) return GGQ_ERR_ALIGN;
+    for (int d = 1; d < n_dst; ++d)
+      if ((uintptr_t)dsts[d] & 15) return GGQ_ERR_ALIGN;
+  }
+  go.arrivals = (uint32_t*)arrivals;
+  go.generation = generation;
+  go.n_dst = n_dst;
+  go.n_flag = n_flag;
+  if (!w || !x || !scratch) return GGQ_ERR_ARG;
+  const int rc = ggq_quantize_q8_1_t16(x, dtype, scratch, batch, k, type, stream);
+  if (rc != GGQ_OK) return rc;
+  return mul_mat_q_t16_impl(w, scratch, dsts[0], type, dtype, batch, k, n_rows, ldy, GGQ_EPI_NONE, nullptr, stream, &go);
+}
+
+int ggq::mul_mat_q_t16_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
+                            int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream, const void* go) {
   using namespace ggq;
   if (epilogue < GGQ_EPI_NONE || epilogue > GGQ_EPI_SILU_MUL || (epilogue != GGQ_EPI_NONE && !aux)) return GGQ_ERR_ARG;
   if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
@@ -709,7 +802,7 @@ extern "C" int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type
     return GGQ_ERR_SHAPE;   // the shifted copy of the last row starts inside the tensor; 32-bit offsets into the whole tensor
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
-  const Epi16 ep{epilogue, aux};
+  const Epi16 ep{epilogue, aux, go ? *(const GatherOut*)go : GatherOut{}};
   hipStream_t s = (hipStream_t)stream;
   switch (type) {
     case GGQ_TYPE_Q4_K: return launch_t16_t<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, s, ep);

@@ -203,6 +203,40 @@ class PeerSlabGather:
             raise err
         return None
 
+    def matmul_gather(self, x: torch.Tensor, w: torch.Tensor, quant_type, scratch: torch.Tensor = None):
+        """y_rank = x · w_rankᵀ written by the GEMM kernel ITSELF into slot `rank` of every rank's buffer, flags published by the
+        kernel's last workgroup (ggq_mul_mat_q_gather: no copy, no second launch), then the wait for the peers' flags.  Falls back to
+        ggq_mul_mat_q_ld into `local` + gather() for the (format, batch, shape) the 16-token-tile kernel does not serve.
+        w: this rank's [rows, row_bytes] shard on the device; x: [batch, k]."""
+        import ctypes
+        from . import lib as ggqlib
+        L = self.L
+        t = int(quant_type)
+        k = x.shape[1]
+        if scratch is None:
+            scratch = torch.empty(int(L.ggq_mmq_scratch_bytes(self.batch, k)), dtype=torch.uint8, device=x.device)
+        par = self._calls & 1
+        gen = (self._calls >> 1) + 1
+        dev = self._mem.device
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        vp = lambda tns: ctypes.c_void_p(tns.data_ptr())
+        peers = sorted(self._peer_ptr)
+        slot = par * self._buf_bytes + self.rank * self._slab_bytes
+        flag_word = self._flags_off + (par * 64 + self.rank) * 4
+        dsts = (ctypes.c_void_p * (len(peers) + 1))(self._mem.data_ptr() + slot, *[self._peer_ptr[p] + slot for p in peers])
+        flg = (ctypes.c_void_p * (len(peers) + 1))(self._mem.data_ptr() + flag_word, *[self._peer_ptr[p] + flag_word for p in peers])
+        rc = L.ggq_mul_mat_q_gather(vp(w), vp(x), dsts, len(peers) + 1, flg, len(peers) + 1, gen, ctypes.c_void_p(self._arrivals), t,
+                                    ggqlib.dtype_code(x.dtype), self.batch, k, self.rows, self.rows, vp(scratch), stream)
+        if rc == -2:   # GGQ_ERR_SHAPE: not a 16-token-tile shape
+            ggqlib.check(L.ggq_mul_mat_q_ld(vp(w), vp(x), vp(self.local), t, ggqlib.dtype_code(x.dtype), self.batch, k, self.rows, self.rows,
+                                           vp(scratch), stream), "ggq_mul_mat_q_ld")
+            return self.gather()
+        ggqlib.check(rc, "ggq_mul_mat_q_gather")
+        my_flags = self._mem.data_ptr() + self._flags_off + par * 64 * 4
+        self._calls += 1
+        ggqlib.check(L.ggq_peer_wait(ctypes.c_void_p(my_flags), self.world, gen, ctypes.c_void_p(self._status), stream), "ggq_peer_wait")
+        return None
+
     def status(self) -> int:
         """0, or 1 if a ggq_peer_wait gave up on a peer (synchronises the device)"""
         return int(self._mem[self._flags_off + 2 * 64 * 4 + 64:self._flags_off + 2 * 64 * 4 + 68].view(torch.int32).item())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 5   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait */
+#define GGQ_ABI_VERSION 6   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -261,6 +261,16 @@ int ggq_peer_scatter(const void* src, int64_t src_pitch, void* const* dsts, void
                      int64_t dst_pitch, int64_t row_bytes, int64_t rows, uint32_t generation, void* arrivals,
                      void* stream);
 int ggq_peer_wait(const void* flags, int n_src, uint32_t generation, void* status, void* stream);
+
+/* The GEMM with a multi-destination write-back: ggq_mul_mat_q_ld + ggq_peer_scatter in ONE kernel.  Y (row pitch ldy elements) is
+ * stored into dsts[0 .. n_dst) — dsts[0] the caller's own slot, the others the same slot of the peers' gather buffers — and once
+ * every workgroup has released its stores at system scope `generation` is written into flags[0 .. n_flag) (ggq_peer_wait on the
+ * consumer side, as after ggq_peer_scatter; `arrivals` as there).  dsts / flags: HOST arrays of device pointers, at most 8 each.
+ * Only for the (type, batch, shape) ggq_mmq_route() sends to the 16-token-tile kernel (GGQ_MMQ_ROUTE_T16); GGQ_ERR_SHAPE
+ * otherwise — the caller then falls back to ggq_mul_mat_q_ld into its own slot + ggq_peer_scatter. */
+int ggq_mul_mat_q_gather(const void* w, const void* x, void* const* dsts, int n_dst, void* const* flags, int n_flag,
+                         uint32_t generation, void* arrivals, int type, int dtype, int64_t batch, int64_t k,
+                         int64_t n_rows, int64_t ldy, void* scratch, void* stream);
 
 #ifdef __cplusplus
 }

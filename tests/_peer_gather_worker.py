@@ -39,6 +39,22 @@ def main():
         for x, got in consumed:
             full = util.gpu_mmq(w, x, t, n_rows)    # the one-GPU result: every slab is computed by the same kernels
             ok = ok and torch.equal(got, full.float() * 2.0)
+    # the GEMM's own multi-destination write-back (ggq_mul_mat_q_gather): batch 8 goes through the 16-token-tile kernel, whose last
+    # workgroup publishes the flags; batch 40 takes the fallback (ggq_mul_mat_q_ld + scatter) inside the same call
+    for b2 in (8, 40):
+        with PeerSlabGather(b2, n_rows, torch.float16, torch.device("cuda", 0)) as pg:
+            wd = torch.from_numpy(w[s:e]).cuda()
+            seen = []
+            for it in range(5):
+                x = torch.randn((b2, k), generator=torch.Generator().manual_seed(40 + it)).half().cuda()
+                if rank == it % world:
+                    torch.cuda._sleep(10_000_000)
+                pg.matmul_gather(x, wd, t)
+                seen.append((x, pg.batch_major().float() + 1.0))
+            torch.cuda.synchronize()
+            assert pg.status() == 0, "a ggq_peer_wait timed out"
+            for x, got in seen:
+                ok = ok and torch.equal(got, util.gpu_mmq(w, x, t, n_rows).float() + 1.0)
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
     dist.destroy_process_group()
