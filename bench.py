@@ -358,7 +358,7 @@ def strong_scaling_config5(L, dev, world, rank, dist):
                 tt = torch.tensor([us_peer], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 entry["end_to_end_peer_write"] = {"us": round(float(tt.item()), 2),
-                                                  "timing": "HIP events, kernel + scatter kernel (peer stores + device flag) + wait kernel, 20 iterations, max over ranks"}
+                                                  "timing": "HIP events; batch 8: the GEMM kernel stores into every rank's slot itself and publishes the flags (ggq_mul_mat_q_gather), others: kernel + scatter kernel (peer stores + device flag); + wait kernel; 20 iterations, max over ranks"}
         nbytes = algo_bytes_matmul(Q4_K, N5, K5, b)
         entry["end_to_end"]["GB/s_whole_job"] = round(nbytes / (entry["end_to_end"]["us"] * 1e-6) / 1e9, 1)
         entry["message_bytes_per_rank"] = b * rows * 2
