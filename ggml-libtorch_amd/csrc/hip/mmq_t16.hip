@@ -683,7 +683,9 @@ static int launch_t16_u(const void* w, const void* q8, void* y, int64_t batch, i
 // at once — short slices mean a short per-wave chain of request -> land -> compute -> reduce and more waves to hide it
 // (stamps: one wave alone needs 0.84 us to issue a 4-unit slice's memory instructions and 0.45 us per unit), but a second
 // round of workgroups costs more than that saves (11008 x 4096, batch 8: 8.1 us with 2-unit slices in two rounds against
-// 6.9 us with 4-unit slices in one).
+// 6.9 us with 4-unit slices in one).  Splitting a resident 4-unit slice into two request -> land -> compute rounds of 2 units
+// (half the LDS image, the second round's requests issued after the first round's compute) measured -2 .. -5 % on the kernel at
+// batch 16 / 32 and +3 % at batch 8, +-0.2 us on the op: not taken (profiles/r03_t16_two_rounds.txt).
 template <int T, int DT, bool M8, int NTT>
 static int launch_t16(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
                       Epi16 ep) {

@@ -9,7 +9,7 @@ t = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 11008
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 batches = [int(a) for a in sys.argv[4:]] or [5, 8, 16, 17, 32]
-L = ggqlib.hip()
+L = ggqlib._bind(ctypes.CDLL(os.environ["GGQ_LIB"]), ggqlib.HIP_SYMBOLS) if os.environ.get("GGQ_LIB") else ggqlib.hip()   # (a variant from scripts/build_variant.sh)
 vp = lambda x: ctypes.c_void_p(x.data_ptr()); st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 w0 = torch.from_numpy(synth.random_weight(t, N, K, seed=0)).cuda()
 nring = max(2, (352 << 20) // w0.numel() + 2)
