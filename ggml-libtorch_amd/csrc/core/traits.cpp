@@ -115,6 +115,19 @@ extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
   return 1;
 }
 
+// Tokens per unit of the streamed kernel (32 rows x 32 or 64 tokens per workgroup).  64-token units read a weight tile once for two
+// token blocks; 32-token units give twice as many, smaller units.  Measured (op, us warm, 32- against 64-token units, 11008 x 4096
+// unless said otherwise; scripts/sweep_mmq_op.py on a -DGGQ_TUNING build, profiles/r03_stream_unit_tokens.txt):
+//   batch 40 / 64   Q4_K 19.6-20.0 / 21.8 vs 20.9-21.4 / 21.6   (3584 x 8192: 17.4 / 18.3 vs 19.7 / 20.7; 4096 x 11008: 23.0 / 24.6 vs 25.9 / 27.4)
+//                   Q5_K 22.4 / 23.0 vs 22.8 / 23.5     Q4_1 24.4 / 25.2 vs 26.8 / 27.6     Q5_1 26.2 / 26.8 vs 28.6 / 29.3
+//                   Q4_0 24.4 / 24.9 vs 22.6 / 23.2     Q5_0 25.5 / 26.2 vs 24.2 / 24.5     Q3_K 31.9 / 32.4 vs 28.5 / 29.0     Q6_K 46.0 / 46.5 vs 35.7 / 36.0
+//   (Q2_K: 32 always — its second int8 tile does not fit the registers with two token blocks; batch <= 32: one token block is the batch)
+extern "C" int ggq_mmq_stream_unit_tokens(int type, int64_t batch) {
+  if (batch <= 32 || type == GGQ_TYPE_Q2_K) return 32;
+  if (batch <= 64 && (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_1)) return 32;
+  return 64;
+}
+
 extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows) {
   if (!ggq_mmq_type_supported(type) || batch <= 0 || k <= 0 || n_rows <= 0 || k % ggq_block_elems(type)) return GGQ_MMQ_ROUTE_NONE;
   // The HBM-bound batches.  Measured (scripts/sweep_t16.py, op = quantise + kernel, us warm / cold, old route -> 16-token tiles):

@@ -208,7 +208,7 @@ STREAM_TYPES = WEIGHT_TYPES
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
 @pytest.mark.parametrize("t", STREAM_TYPES, ids=lambda t: t.name)
-@pytest.mark.parametrize("batch,k,n_rows", [(5, 256, 33), (17, 768, 31), (32, 1024, 64), (33, 256, 1), (64, 2304, 70),
+@pytest.mark.parametrize("batch,k,n_rows", [(5, 256, 33), (17, 768, 31), (32, 1024, 64), (33, 256, 1), (64, 2304, 70), (48, 1024, 100),
                                             (65, 1280, 95), (128, 4096, 160), (129, 512, 32), (300, 256, 257)])
 def test_mmq_streamed_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     """The streamed kernel (32- and 64-token units, ragged row / token tiles, 1..18 K stages per wave,

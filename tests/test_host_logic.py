@@ -107,6 +107,13 @@ def test_mmq_routing_table():
     # Q6_K: the whole tensor within 32-bit offsets and at least 1 KB (its last row's copy is shifted into the row before)
     assert L.ggq_mmq_route(Q6_K, 8, 256, 4) != T16 and L.ggq_mmq_route(Q6_K, 8, 256, 8) == T16
     assert L.ggq_mmq_route(Q6_K, 8, 1 << 20, 8192) != T16
+    # tokens per unit of the streamed kernel (the mmq_x side of the heuristic): 32 while one token block is the batch, 32 up to
+    # batch 64 for the four formats where the smaller units measured faster, 32 always for Q2_K, else 64
+    Q2_K = 10
+    for t in WEIGHT_TYPES:
+        for b in (1, 5, 32, 33, 48, 64, 65, 128, 4096):
+            want = 32 if (b <= 32 or int(t) == Q2_K or (b <= 64 and int(t) in (Q4_K, Q5_K, Q4_1, Q5_1))) else 64
+            assert L.ggq_mmq_stream_unit_tokens(int(t), b) == want, (t, b)
 
 
 def test_shipped_code_objects_keep_the_mfma_wait_states():
