@@ -122,9 +122,13 @@ extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
 //                   Q5_K 22.4 / 23.0 vs 22.8 / 23.5     Q4_1 24.4 / 25.2 vs 26.8 / 27.6     Q5_1 26.2 / 26.8 vs 28.6 / 29.3
 //                   Q4_0 24.4 / 24.9 vs 22.6 / 23.2     Q5_0 25.5 / 26.2 vs 24.2 / 24.5     Q3_K 31.9 / 32.4 vs 28.5 / 29.0     Q6_K 46.0 / 46.5 vs 35.7 / 36.0
 //   (Q2_K: 32 always — its second int8 tile does not fit the registers with two token blocks; batch <= 32: one token block is the batch)
-extern "C" int ggq_mmq_stream_unit_tokens(int type, int64_t batch) {
+//   Q8_0 (kernel alone, scripts/route_audit.sh, profiles/r03_route_audit.txt): 3584 x 8192 batch 48 / 64 20.6 / 20.8 vs 23.6 / 23.7, 4096 x 11008
+//                   26.7 / 26.3 vs 28.7 / 28.8; 11008 x 4096 30.1 / 30.4 vs 26.7 / 27.5 (where ggq_mmq_route keeps the LDS-tile kernel anyway)
+//   batch 80 / 96: 64-token units win or tie for every format at every shape (same file)
+extern "C" int ggq_mmq_stream_unit_tokens(int type, int64_t batch, int64_t n_rows) {
   if (batch <= 32 || type == GGQ_TYPE_Q2_K) return 32;
   if (batch <= 64 && (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_1)) return 32;
+  if (batch <= 64 && type == GGQ_TYPE_Q8_0 && n_rows < 8192) return 32;
   return 64;
 }
 
@@ -176,7 +180,10 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // kernel for the mid batches of the two formats whose streamed instance is bound by its weight copy, streamed beyond.
   const bool dot4_to_8 = type == GGQ_TYPE_Q4_0 || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_0 || type == GGQ_TYPE_Q5_1 ||
                          type == GGQ_TYPE_Q4_K;
-  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? 65 : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 : 5;
+  // Q8_0 batch 17 - 64: the LDS-tile kernel wins where the matrix has many rows (11008 x 4096: 19.4 / 25.6 us at batch 32 / 64 against
+  // 23.4 / 26.7 streamed) and loses by a third where it has few (3584 x 8192: 28.5 / 32.2 against 19.6 / 20.8; 4096 x 11008: 37.0 / 41.8
+  // against 23.8 / 26.3) — kernel alone, warm, profiles/r03_route_audit.txt.  Q6_K 17 - 32 is a tie either way (+-2 us by shape).
+  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? (n_rows < 8192 ? 17 : 65) : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 : 5;
   const bool streamable = ggq_row_bytes(type, k) <= (32 << 20);   // ggq_mmq_tiled_supported: 32-bit offsets in a 32-row tile
   if (streamable && batch >= stream_from) return GGQ_MMQ_ROUTE_STREAM;
   return batch <= 8 ? GGQ_MMQ_ROUTE_DOT4 : GGQ_MMQ_ROUTE_LDS_TILE;

@@ -1413,7 +1413,7 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
   // (measured r1, Q4_K 11008x4096: batch 32 14.4 vs 20.0 us, batch 128 38.8 vs 29.9 us; r3: ggq_mmq_stream_unit_tokens)
   static const char* e = GGQ_TUNING_ENV("GGQ_MMQ_TB");   // experiments: force 32- or 64-token units
   // (Q2_K's second int8 tile does not fit 168 VGPRs with two token blocks: 168 us spilled vs 54 us)
-  const bool one = e ? e[0] == '1' : ggq_mmq_stream_unit_tokens(T, batch) == 32;   // (csrc/core/traits.cpp: per format, measured)
+  const bool one = e ? e[0] == '1' : ggq_mmq_stream_unit_tokens(T, batch, n) == 32;   // (csrc/core/traits.cpp: per format, measured)
   switch (dt) {
     case GGQ_F32: return one ? launch_mmq_stream<T, GGQ_F32, 1>(w, q8, y, batch, k, n, ldy, s, ep) : launch_mmq_stream<T, GGQ_F32, 2>(w, q8, y, batch, k, n, ldy, s, ep);
     case GGQ_F16: return one ? launch_mmq_stream<T, GGQ_F16, 1>(w, q8, y, batch, k, n, ldy, s, ep) : launch_mmq_stream<T, GGQ_F16, 2>(w, q8, y, batch, k, n, ldy, s, ep);

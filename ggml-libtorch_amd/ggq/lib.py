@@ -38,7 +38,7 @@ HIP_SYMBOLS = {
     "ggq_mul_mat_q_pretiled_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ggq_mul_mat_q_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ggq_mmq_route": (c_int, [c_int, c_int64, c_int64, c_int64]),
-    "ggq_mmq_stream_unit_tokens": (c_int, [c_int, c_int64]),
+    "ggq_mmq_stream_unit_tokens": (c_int, [c_int, c_int64, c_int64]),
     "ggq_mmq_t16_type_supported": (c_int, [c_int]),
     "ggq_mmq_t16_supported": (c_int, [c_int, c_int64, c_int64]),
     "ggq_quantize_q8_1_t16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -55,7 +55,7 @@ HIP_SYMBOLS = {
 }
 CPU_SYMBOLS = {
     "ggq_mmq_route": (c_int, [c_int, c_int64, c_int64, c_int64]),
-    "ggq_mmq_stream_unit_tokens": (c_int, [c_int, c_int64]),
+    "ggq_mmq_stream_unit_tokens": (c_int, [c_int, c_int64, c_int64]),
     "ggq_cpu_dequantize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int]),
     "ggq_cpu_dequantize_f32_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int]),
     "ggq_cpu_simd_name": (ctypes.c_char_p, []),

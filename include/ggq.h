@@ -201,9 +201,9 @@ int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype
 enum ggq_mmq_route_id { GGQ_MMQ_ROUTE_NONE = 0, GGQ_MMQ_ROUTE_DOT4 = 1, GGQ_MMQ_ROUTE_LDS_TILE = 2, GGQ_MMQ_ROUTE_STREAM = 3,
                         GGQ_MMQ_ROUTE_T16 = 4 };
 int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows);
-/* Tokens per workgroup unit (32 or 64) the STREAM route uses for a (type, batch): the other half of the tile heuristic's role
+/* Tokens per workgroup unit (32 or 64) the STREAM route uses for a (type, batch, n_rows): the other half of the tile heuristic's role
  * (mmq_x of mul_mat_q_case, HK/ggml/kernel_instances/mmq_kernel.cuh:21-32).  Host-only. */
-int ggq_mmq_stream_unit_tokens(int type, int64_t batch);
+int ggq_mmq_stream_unit_tokens(int type, int64_t batch, int64_t n_rows);
 
 /* mul_mat_vec_q alone on an already-quantised scratch (layout of ggq_quantize_q8_1). */
 int ggq_mul_mat_vec_q_prequant(const void* w, const void* q, void* y, int type, int dtype,

@@ -84,7 +84,8 @@ def test_mmq_routing_table():
         assert L.ggq_mmq_route(Q5_K, 32, k, n) == STREAM
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16) and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == STREAM
-        assert L.ggq_mmq_route(Q8_0, 17, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 64, k, n) == LDS_TILE and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
+        mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows
+        assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8, 16)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
         assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == (DOT4 if n >= 8192 else T16)
@@ -111,9 +112,10 @@ def test_mmq_routing_table():
     # batch 64 for the four formats where the smaller units measured faster, 32 always for Q2_K, else 64
     Q2_K = 10
     for t in WEIGHT_TYPES:
-        for b in (1, 5, 32, 33, 48, 64, 65, 128, 4096):
-            want = 32 if (b <= 32 or int(t) == Q2_K or (b <= 64 and int(t) in (Q4_K, Q5_K, Q4_1, Q5_1))) else 64
-            assert L.ggq_mmq_stream_unit_tokens(int(t), b) == want, (t, b)
+        for n in (3584, 8191, 8192, 11008):
+            for b in (1, 5, 32, 33, 48, 64, 65, 128, 4096):
+                want = 32 if (b <= 32 or int(t) == Q2_K or (b <= 64 and (int(t) in (Q4_K, Q5_K, Q4_1, Q5_1) or (int(t) == Q8_0 and n < 8192)))) else 64
+                assert L.ggq_mmq_stream_unit_tokens(int(t), b, n) == want, (t, b, n)
 
 
 def test_shipped_code_objects_keep_the_mfma_wait_states():
