@@ -183,7 +183,13 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // Q8_0 batch 17 - 64: the LDS-tile kernel wins where the matrix has many rows (11008 x 4096: 19.4 / 25.6 us at batch 32 / 64 against
   // 23.4 / 26.7 streamed) and loses by a third where it has few (3584 x 8192: 28.5 / 32.2 against 19.6 / 20.8; 4096 x 11008: 37.0 / 41.8
   // against 23.8 / 26.3) — kernel alone, warm, profiles/r03_route_audit.txt.  Q6_K 17 - 32 is a tie either way (+-2 us by shape).
-  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? (n_rows < 8192 ? 17 : 65) : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 : 5;
+  const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? (n_rows < 8192 ? 17 : 65) : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 :
+                              (type == GGQ_TYPE_Q2_K && n_rows < 8192) ? 3 : 5;
+  // Q2_K (two int8 tiles per group; profiles/r03_route_audit2.txt, _audit3.txt, kernel alone, warm): its streamed instance is good up to 16 tokens
+  // (transposed operands: 15.4 / 17.1 / 22.3 us at batch 16 on 11008 x 4096 / 3584 x 8192 / 4096 x 11008 against 22.5 / 25.4 / 33.1 on the
+  // LDS-tile kernel) and from 33 (26.0 / 31.0 / 42.3 against 37.6 / 35.3 / 46.4), but at 17 - 32 the LDS-tile kernel wins: 22.7 / 25.4 / 33.0
+  // against 23.2 - 24.6 / 29.8 / 40.7.  With few rows the dot4 kernel is overtaken at batch 3 (op, 3584 x 8192: 13.7 / 18.1 us at batch 2 / 3 on dot4, 16.1 at batch 4 streamed), not 5.
+  if (type == GGQ_TYPE_Q2_K && batch >= 17 && batch <= 32) return GGQ_MMQ_ROUTE_LDS_TILE;
   const bool streamable = ggq_row_bytes(type, k) <= (32 << 20);   // ggq_mmq_tiled_supported: 32-bit offsets in a 32-row tile
   if (streamable && batch >= stream_from) return GGQ_MMQ_ROUTE_STREAM;
   return batch <= 8 ? GGQ_MMQ_ROUTE_DOT4 : GGQ_MMQ_ROUTE_LDS_TILE;

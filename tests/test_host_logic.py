@@ -88,6 +88,9 @@ def test_mmq_routing_table():
         assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8, 16)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
+        # Q2_K: dot4 to batch 4 (2 with few rows), streamed to 16 and from 33, the LDS-tile kernel in between
+        assert [L.ggq_mmq_route(10, b, k, n) for b in (2, 3, 4, 5, 16, 17, 32, 33, 128)] == \
+            [DOT4, DOT4 if n >= 8192 else STREAM, DOT4 if n >= 8192 else STREAM, STREAM, STREAM, LDS_TILE, LDS_TILE, STREAM, STREAM]
         assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == (DOT4 if n >= 8192 else T16)
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
