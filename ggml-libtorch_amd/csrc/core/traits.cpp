@@ -165,7 +165,9 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   switch (type) {
     case GGQ_TYPE_Q4_K: t16_to = 32; break;
     case GGQ_TYPE_Q5_K: case GGQ_TYPE_Q6_K: t16_to = 16; break;
-    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q8_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
+    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
+    case GGQ_TYPE_Q8_0: t16_to = 16; break;   // from batch 2 at every shape: with many rows a tie warm (13.4 against 12.9 - 13.7 us on dot4) and
+                                              // 15.1 - 15.5 against 17.2 - 18.6 with the weights from HBM (profiles/r03_sweep_batch_all.txt)
     case GGQ_TYPE_Q5_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 9; break;
     case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q3_K: t16_to = n_rows < 8192 ? 16 : 0; break;
     default: break;
