@@ -132,6 +132,22 @@ extern "C" int ggq_mmq_stream_unit_tokens(int type, int64_t batch, int64_t n_row
   return 64;
 }
 
+// Batch 17 - 32 (two 16-token tiles per wave) against the streamed kernel's 32-token units, by matrix shape — scripts/sweep_t16_vs_stream.py,
+// profiles/r03_t16_vs_stream_b17_32.txt, op us warm / cold at batch 32, 16-token tiles | streamed:
+//   Q4_K  K = 4096   rows 2048  8.7 /  9.4 | 11.7 / 12.8    4096  9.1 / 10.1 | 11.2 / 13.0    6144 16.7 / 17.9 | 11.4 / 13.9    8192 17.2 / 18.7 | 11.8 / 15.4
+//                         11008 16.4 / 18.5 | 15.8 / 19.6   14336 21.8 / 24.1 | 17.2 / 20.9   16384 22.9 / 23.7 | 17.8 / 21.6   28672 36.0 / 35.0 | 30.0 / 37.3
+//         K = 8192   rows 2048 12.5 / 13.8 | 16.0 / 18.6    4096 13.4 / 14.9 | 16.6 / 20.5    8192 30.3 / 31.4 | 19.5 / 22.3   16384 47.0 / 46.0 | 29.6 / 34.5
+//                         28672 76.6 / 75.8 | 49.4 / 64.8      4096 x 11008 16.8 / 19.2 | 21.0 / 26.5      4096 x 14336 22.3 / 23.0 | 24.4 / 30.8
+//   Q5_K  the same picture, 1 - 2 us higher on both sides (4096 x 11008: 18.0 / 20.3 | 24.1 / 28.5; 8192 x 4096: 19.3 / 20.8 | 12.6 / 15.9)
+// The 16-token tiles need every workgroup resident at once: up to 4096 rows that is one workgroup per CU with 8 - 12 short K-slices, beyond it two
+// or three with slices twice as long, and the kernel takes twice the time.  The streamed kernel's time goes with the units per CU, ceil(units / 256):
+// it loses only where that rounding leaves a third of the CU-rounds empty (344 units on 256 CUs at 11008 rows: a tie).
+static bool t16_two_tiles_pay(int64_t n_rows) {
+  if (n_rows <= 4096) return true;
+  const int64_t units = (n_rows + 31) / 32, per_cu = (units + 255) / 256;
+  return units > 256 && units * 10 < per_cu * 256 * 7;
+}
+
 extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows) {
   if (!ggq_mmq_type_supported(type) || batch <= 0 || k <= 0 || n_rows <= 0 || k % ggq_block_elems(type)) return GGQ_MMQ_ROUTE_NONE;
   // The HBM-bound batches.  Measured (scripts/sweep_t16.py, op = quantise + kernel, us warm / cold, old route -> 16-token tiles):
@@ -163,8 +179,8 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   //   3584 x 8192 b2 26.5/28.8 -> 12.8/15.3   b8 20.8/23.4 -> 13.3/15.4   b16 22.5/24.7 -> 16.5/19.1     4096 x 11008 b2 35.3/36.7 -> 18.5/20.9   b8 26.9/29.3 -> 18.7/21.2
   int64_t t16_from = 2, t16_to = 0;
   switch (type) {
-    case GGQ_TYPE_Q4_K: t16_to = 32; break;
-    case GGQ_TYPE_Q5_K: case GGQ_TYPE_Q6_K: t16_to = 16; break;
+    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: t16_to = t16_two_tiles_pay(n_rows) ? 32 : 16; break;
+    case GGQ_TYPE_Q6_K: t16_to = 16; break;
     case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
     case GGQ_TYPE_Q8_0: t16_to = 16; break;   // from batch 2 at every shape: with many rows a tie warm (13.4 against 12.9 - 13.7 us on dot4) and
                                               // 15.1 - 15.5 against 17.2 - 18.6 with the weights from HBM (profiles/r03_sweep_batch_all.txt)

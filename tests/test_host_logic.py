@@ -77,11 +77,11 @@ def test_mmq_routing_table():
                 prev = r
     # the HBM-bound batches of the formats with a 16-token-tile kernel, at every BASELINE shape
     for k, n in shapes[:4]:
-        for b in (2, 5, 8, 16, 32):
-            assert L.ggq_mmq_route(Q4_K, b, k, n) == T16
-        for b in (2, 8, 16):
-            assert L.ggq_mmq_route(Q5_K, b, k, n) == T16
-        assert L.ggq_mmq_route(Q5_K, 32, k, n) == STREAM
+        for b in (2, 5, 8, 16):
+            assert L.ggq_mmq_route(Q4_K, b, k, n) == T16 and L.ggq_mmq_route(Q5_K, b, k, n) == T16
+        # two token tiles per wave (batch 17 - 32): up to 4096 rows, or where the streamed launch would leave a third of its CU-rounds empty
+        two = T16 if n in (11008, 4096, 3584) else STREAM
+        assert L.ggq_mmq_route(Q4_K, 32, k, n) == two and L.ggq_mmq_route(Q5_K, 17, k, n) == two
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16) and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == STREAM
         mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows
@@ -103,6 +103,10 @@ def test_mmq_routing_table():
                 if not want_t16:
                     assert r == (DOT4 if b <= (4 if t32 == Q3_K else 8) else (LDS_TILE if t32 == Q8_0 else STREAM))
             assert L.ggq_mmq_route(t32, 17, k, n) != T16
+    for n, want in ((2048, T16), (4096, T16), (4128, STREAM), (6144, STREAM), (8192, STREAM), (8224, T16), (11008, T16), (11488, STREAM), (14336, STREAM),
+                    (16384, STREAM), (16416, T16), (28672, STREAM)):
+        assert L.ggq_mmq_route(Q4_K, 32, 4096, n) == want and L.ggq_mmq_route(Q5_K, 32, 8192, n) == want, n
+        assert L.ggq_mmq_route(Q4_K, 16, 4096, n) == T16
     # invalid inputs
     assert L.ggq_mmq_route(1, 8, 4096, 64) == NONE and L.ggq_mmq_route(Q4_K, 0, 4096, 64) == NONE
     assert L.ggq_mmq_route(20, 8, 4096, 64) == NONE   # IQ4_NL: no GEMM
