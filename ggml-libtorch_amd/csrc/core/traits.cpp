@@ -125,10 +125,21 @@ extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
 //   Q8_0 (kernel alone, scripts/route_audit.sh, profiles/r03_route_audit.txt): 3584 x 8192 batch 48 / 64 20.6 / 20.8 vs 23.6 / 23.7, 4096 x 11008
 //                   26.7 / 26.3 vs 28.7 / 28.8; 11008 x 4096 30.1 / 30.4 vs 26.7 / 27.5 (where ggq_mmq_route keeps the LDS-tile kernel anyway)
 //   batch 80 / 96: 64-token units win or tie for every format at every shape (same file)
+//   By shape (scripts/route_audit4.sh / route_audit5.sh, profiles/r03_route_audit4.txt, _audit5.txt; kernel alone at batch 48, us warm / cold, 32- | 64-token units):
+//     Q4_K K = 4096  rows 2048 8.5 / 9.1 | 10.1 / 10.6   4096 9.2 / 10.0 | 10.7 / 11.5   6144 13.3 / 14.4 | 11.1 / 12.8   8192 14.6 / 17.1 | 11.7 / 14.8
+//                    14336 24.5 / 30.6 | 20.1 / 23.9   16384 26.0 / 32.4 | 21.8 / 25.1   28672 40.3 / 49.1 | 37.5 / 43.2      8192 x 8192 25.3 / 28.3 | 21.2 / 24.6
+//     every other format at 4096 x 4096, 3584 x 8192, 4096 x 11008: 32-token units 8 - 20 % faster; at 8192 x 4096: 64-token units 15 - 25 % faster
+//   i.e. the time follows the workgroups per CU: up to 4096 rows two 32-token units per row tile are still one workgroup per CU (and half the
+//   work each); beyond that they are two or more where 64-token units are one, except in the band where 64-token units round badly
+//   (256 < row tiles <= 384, e.g. 344 at 11008 rows) and the 32-token ones still fit one resident round (<= 768): there the four formats
+//   measured above at 11008 x 4096 take 32, the others 64.
 extern "C" int ggq_mmq_stream_unit_tokens(int type, int64_t batch, int64_t n_rows) {
   if (batch <= 32 || type == GGQ_TYPE_Q2_K) return 32;
-  if (batch <= 64 && (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_1)) return 32;
-  if (batch <= 64 && type == GGQ_TYPE_Q8_0 && n_rows < 8192) return 32;
+  if (batch > 64) return 64;
+  if (n_rows <= 4096) return 32;
+  const int64_t row_tiles = (n_rows + 31) / 32;
+  if (row_tiles > 256 && row_tiles <= 384 &&
+      (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_1)) return 32;
   return 64;
 }
 
