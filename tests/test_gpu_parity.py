@@ -329,6 +329,26 @@ def test_mmq_full_size_rows_sample(oracle, t):
     assert torch.equal(y2, y[:, torch.from_numpy(perm).cuda()])
 
 
+@pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q4_1, GGMLType.Q8_0, GGMLType.Q2_K, GGMLType.Q4_0], ids=lambda t: t.name)
+@pytest.mark.parametrize("n_rows", [4096, 4128, 8224, 11008, 12320])
+def test_mmq_op_across_the_shape_terms_of_the_routing(oracle, t, n_rows):
+    """ggq_mul_mat_q on both sides of every row-count threshold of ggq_mmq_route / ggq_mmq_stream_unit_tokens (4096 rows; the
+    8192 < rows <= 12288 band; Q8_0's and Q2_K's own terms), at the batches where they switch kernels or unit sizes: oracle on a
+    sample of rows (first / middle / last tiles), whatever kernel the table picks."""
+    k = 512
+    L = ggqlib.hip()
+    w = synth.random_weight(t, n_rows, k, seed=n_rows % 97)
+    rows = np.r_[0:20, n_rows // 2 - 10:n_rows // 2 + 10, n_rows - 20:n_rows]
+    seen = set()
+    for batch in (3, 16, 17, 32, 33, 48, 64, 65):
+        x = _x((batch, k), torch.float16, seed=batch)
+        y = util.gpu_mmq(w, x, t, n_rows)
+        ref, yabs = oracle.mul_mat_q(w[rows], x.float().cpu().numpy(), t, len(rows))
+        util.assert_fp_accumulate(y[:, torch.from_numpy(rows).cuda()], ref, yabs, torch.float16, f"mmq {t.name} b={batch} rows={n_rows}")
+        seen.add((L.ggq_mmq_route(int(t), batch, k, n_rows), L.ggq_mmq_stream_unit_tokens(int(t), batch, n_rows)))
+    assert len(seen) >= 2   # several (kernel, unit size) pairs were exercised (Q2_K: two kernels, 32-token units only)
+
+
 @pytest.mark.parametrize("t", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q5_1], ids=lambda t: t.name)
 def test_mmq_transposed_shape_rows_sample(oracle, t):
     """SURVEY §8 secondary shape: K = 11008 (11008 % 512 = 256 exercises the scratch padding; 43 / 86 K stages
