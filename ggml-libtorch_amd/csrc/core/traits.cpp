@@ -135,10 +135,11 @@ extern "C" int ggq_mmq_t16_supported(int type, int64_t k, int64_t batch) {
 //   measured above at 11008 x 4096 take 32, the others 64.
 extern "C" int ggq_mmq_stream_unit_tokens(int type, int64_t batch, int64_t n_rows) {
   if (batch <= 32 || type == GGQ_TYPE_Q2_K) return 32;
-  if (batch > 64) return 64;
-  if (n_rows <= 4096) return 32;
-  const int64_t row_tiles = (n_rows + 31) / 32;
-  if (row_tiles > 256 && row_tiles <= 384 &&
+  // one workgroup per CU at most with 32-token units: they win at every batch (route_audit6: batch 96 / 128, 1024 - 2048 rows: Q4_K 8.3 - 9.3 / 8.8 - 9.7
+  // against 10.1 - 10.7 / 10.6 - 11.2, Q4_0 the same 13 - 18 %; 3072 rows, 288 - 384 units: 13.1 - 14.2 against 11.1 - 11.2) — at batch 33 - 64 that is "up to 4096 rows"
+  const int64_t row_tiles = (n_rows + 31) / 32, tok_tiles = (batch + 31) / 32;
+  if (row_tiles * tok_tiles <= 256) return 32;
+  if (batch <= 64 && row_tiles > 256 && row_tiles <= 384 &&
       (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K || type == GGQ_TYPE_Q4_1 || type == GGQ_TYPE_Q5_1)) return 32;
   return 64;
 }

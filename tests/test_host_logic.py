@@ -116,14 +116,16 @@ def test_mmq_routing_table():
     assert L.ggq_mmq_route(Q6_K, 8, 256, 4) != T16 and L.ggq_mmq_route(Q6_K, 8, 256, 8) == T16
     assert L.ggq_mmq_route(Q6_K, 8, 1 << 20, 8192) != T16
     # tokens per unit of the streamed kernel (the mmq_x side of the heuristic): 32 while one token block is the batch and always for Q2_K;
-    # at batch 33 - 64 by shape — 32 up to 4096 rows, 32 in the band where 64-token units round badly (8192 < rows <= 12288) for the four
-    # formats that measured faster there, else 64; 64 beyond batch 64
+    # beyond that by shape — 32 while every 32-token unit still has a CU to itself (row tiles x token tiles <= 256: up to 4096 rows at batch
+    # 33 - 64, 2048 at 97 - 128), 32 at batch 33 - 64 in the band where 64-token units round badly (8192 < rows <= 12288) for the four formats that
+    # measured faster there, else 64
     Q2_K = 10
     for t in WEIGHT_TYPES:
-        for n in (64, 3584, 4096, 4097, 8192, 8193, 11008, 12288, 12289, 28672):
-            for b in (1, 5, 32, 33, 48, 64, 65, 128, 4096):
-                mid = n <= 4096 or (8192 < n <= 12288 and int(t) in (Q4_K, Q5_K, Q4_1, Q5_1))
-                want = 32 if (b <= 32 or int(t) == Q2_K or (b <= 64 and mid)) else 64
+        for n in (64, 1024, 2048, 2049, 2730, 3584, 4096, 4097, 8192, 8193, 11008, 12288, 12289, 28672):
+            for b in (1, 5, 32, 33, 48, 64, 65, 96, 97, 128, 4096):
+                one_per_cu = -(-n // 32) * -(-b // 32) <= 256   # every 32-token unit has a CU to itself
+                band = b <= 64 and 8192 < n <= 12288 and int(t) in (Q4_K, Q5_K, Q4_1, Q5_1)
+                want = 32 if (b <= 32 or int(t) == Q2_K or one_per_cu or band) else 64
                 assert L.ggq_mmq_stream_unit_tokens(int(t), b, n) == want, (t, b, n)
 
 
