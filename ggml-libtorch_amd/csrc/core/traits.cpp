@@ -196,8 +196,16 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
     case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
     case GGQ_TYPE_Q8_0: t16_to = 16; break;   // from batch 2 at every shape: with many rows a tie warm (13.4 against 12.9 - 13.7 us on dot4) and
                                               // 15.1 - 15.5 against 17.2 - 18.6 with the weights from HBM (profiles/r03_sweep_batch_all.txt)
-    case GGQ_TYPE_Q5_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 9; break;
-    case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q3_K: t16_to = n_rows < 8192 ? 16 : 0; break;
+    // Beyond ~12288 rows the dot4 kernel (sized for 4096 waves) stops scaling and the 5-bit formats' 16-token tiles overtake it from batch 5
+    // (scripts/sweep_t16.py, profiles/r03_t16_many_rows.txt, op us warm / cold, routed before | 16-token tiles):
+    //   Q5_1 batch 8   14336 x 4096 25.1 / 25.3 | 14.1 / 15.9   16384 25.6 / 26.1 | 14.5 / 16.2   20480 26.3 / 27.8 | 17.7 / 20.1   28672 36.4 / 37.4 | 22.7 / 25.3
+    //                  14336 x 8192 41.4 / 41.9 | 23.8 / 25.9   20480 x 8192 43.7 / 44.3 | 38.9 / 40.3        batch 16 (streamed before) 14336 22.0 / 24.2 | 18.4 / 19.6
+    //                  20480 28.9 / 30.6 | 20.9 / 22.9   28672 35.9 / 37.9 | 29.6 / 30.7   (K = 8192: level)
+    //   Q5_0 batch 8   14336 24.3 / 25.5 | 17.2 / 18.3   16384 24.6 / 25.7 | 17.7 / 20.6   20480 25.4 / 26.5 | 22.3 / 22.7   28672 32.4 / 35.0 | 26.3 / 27.0   (batch 4: level)
+    //   (Q4_0 / Q4_1 batch 2 - 4 there: mixed — ahead at K = 4096, far behind at 28672 x 8192; Q3_K: level at 8, behind at 16 — unchanged)
+    case GGQ_TYPE_Q5_0: t16_to = 16; t16_from = n_rows < 8192 ? 2 : n_rows > 12288 ? 5 : 9; break;
+    case GGQ_TYPE_Q5_1: t16_to = (n_rows < 8192 || n_rows > 12288) ? 16 : 0; t16_from = n_rows < 8192 ? 2 : 5; break;
+    case GGQ_TYPE_Q3_K: t16_to = n_rows < 8192 ? 16 : 0; break;
     default: break;
   }
   // one token through this entry point: with few rows the 16-token tiles beat the dot4 kernel there too (Q4_K 4096 x 11008 10.7 / 12.4 us

@@ -95,7 +95,8 @@ def test_mmq_routing_table():
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
         many = n >= 8192
-        for t32, frm in ((Q4_0, 5), (Q4_1, 5), (Q8_0, 2), (Q5_0, 9), (Q5_1, 17), (Q3_K, 17)):
+        huge = n > 12288   # beyond the dot4 kernel's scaling range the 5-bit formats take the 16-token tiles from batch 5
+        for t32, frm in ((Q4_0, 5), (Q4_1, 5), (Q8_0, 2), (Q5_0, 5 if huge else 9), (Q5_1, 5 if huge else 17), (Q3_K, 17)):
             for b in (2, 4, 5, 8, 9, 16):
                 want_t16 = b >= (frm if many else 2)
                 r = L.ggq_mmq_route(t32, b, k, n)
