@@ -222,7 +222,10 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // 23.4 / 26.7 streamed) and loses by a third where it has few (3584 x 8192: 28.5 / 32.2 against 19.6 / 20.8; 4096 x 11008: 37.0 / 41.8
   // against 23.8 / 26.3) — kernel alone, warm, profiles/r03_route_audit.txt.  Q6_K 17 - 32 is a tie either way (+-2 us by shape).
   const int64_t stream_from = type == GGQ_TYPE_Q8_0 ? (n_rows < 8192 ? 17 : 65) : type == GGQ_TYPE_Q6_K ? 33 : dot4_to_8 ? 9 :
-                              (type == GGQ_TYPE_Q2_K && n_rows < 8192) ? 3 : 5;
+                              // (past 12288 rows the dot4 kernel stops scaling: streamed from batch 3 / 2 there — 14336 x 4096 Q2_K batch 3
+                              // 17.1 -> 12.5 us, Q3_K batch 2 22.7 -> 17.7; 28672 rows 23.8 -> 21.6, 32.4 -> 29.4; profiles/r03_t16_many_rows.txt)
+                              (type == GGQ_TYPE_Q2_K && (n_rows < 8192 || n_rows > 12288)) ? 3 :
+                              (type == GGQ_TYPE_Q3_K && n_rows > 12288) ? 2 : 5;
   // Q2_K (two int8 tiles per group; profiles/r03_route_audit2.txt, _audit3.txt, kernel alone, warm): its streamed instance is good up to 16 tokens
   // (transposed operands: 15.4 / 17.1 / 22.3 us at batch 16 on 11008 x 4096 / 3584 x 8192 / 4096 x 11008 against 22.5 / 25.4 / 33.1 on the
   // LDS-tile kernel) and from 33 (26.0 / 31.0 / 42.3 against 37.6 / 35.3 / 46.4), but at 17 - 32 the LDS-tile kernel wins: 22.7 / 25.4 / 33.0

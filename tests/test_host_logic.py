@@ -90,7 +90,7 @@ def test_mmq_routing_table():
         assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8, 16)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
         # Q2_K: dot4 to batch 4 (2 with few rows), streamed to 16 and from 33, the LDS-tile kernel in between
         assert [L.ggq_mmq_route(10, b, k, n) for b in (2, 3, 4, 5, 16, 17, 32, 33, 128)] == \
-            [DOT4, DOT4 if n >= 8192 else STREAM, DOT4 if n >= 8192 else STREAM, STREAM, STREAM, LDS_TILE, LDS_TILE, STREAM, STREAM]
+            [DOT4, DOT4 if 8192 <= n <= 12288 else STREAM, DOT4 if 8192 <= n <= 12288 else STREAM, STREAM, STREAM, LDS_TILE, LDS_TILE, STREAM, STREAM]
         assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == (DOT4 if n >= 8192 else T16)
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
@@ -102,7 +102,8 @@ def test_mmq_routing_table():
                 r = L.ggq_mmq_route(t32, b, k, n)
                 assert (r == T16) == want_t16, (t32, b, k, n, r)
                 if not want_t16:
-                    assert r == (DOT4 if b <= (4 if t32 == Q3_K else 8) else (LDS_TILE if t32 == Q8_0 else STREAM))
+                    dot4_to = (4 if n <= 12288 else 1) if t32 == Q3_K else 8   # Q3_K: streamed from batch 5, from 2 past 12288 rows
+                    assert r == (DOT4 if b <= dot4_to else (LDS_TILE if t32 == Q8_0 else STREAM))
             assert L.ggq_mmq_route(t32, 17, k, n) != T16
     for n, want in ((2048, T16), (4096, T16), (4128, STREAM), (6144, STREAM), (8192, STREAM), (8224, T16), (11008, T16), (11488, STREAM), (14336, STREAM),
                     (16384, STREAM), (16416, T16), (28672, STREAM)):
