@@ -192,7 +192,11 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   int64_t t16_from = 2, t16_to = 0;
   switch (type) {
     case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q5_K: t16_to = t16_two_tiles_pay(n_rows) ? 32 : 16; break;
-    case GGQ_TYPE_Q6_K: t16_to = 16; break;
+    // Q6_K on vocabulary-sized matrices (profiles/r03_vocab_rows.txt, kernel alone, warm): once its workgroups (3.4 KB of LDS image per unit) are no
+    // longer all resident the 16-token-tile kernel collapses — 65536 x 4096 batch 8: 120 us against 68 on dot4; 128256 rows: 277 against 152;
+    // batch 16 at 28672 rows: 59 against 44 streamed — while up to 14336 rows (batch 16) / 28672 rows (batch 8: 28.4 against 36.8) it wins.
+    // (The other formats' instances hold up there: Q8_0 128256 x 4096 batch 8 119 us against 143, Q5_K 80 against 103.)
+    case GGQ_TYPE_Q6_K: t16_to = n_rows <= 16384 ? 16 : n_rows <= 32768 ? 8 : 0; break;
     case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
     case GGQ_TYPE_Q8_0: t16_to = 16; break;   // from batch 2 at every shape: with many rows a tie warm (13.4 against 12.9 - 13.7 us on dot4) and
                                               // 15.1 - 15.5 against 17.2 - 18.6 with the weights from HBM (profiles/r03_sweep_batch_all.txt)

@@ -87,7 +87,8 @@ def test_mmq_routing_table():
         mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows
         assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
-        assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8, 16)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
+        assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
+        assert L.ggq_mmq_route(Q6_K, 16, k, n) == (T16 if n <= 16384 else LDS_TILE)   # its 16-token tiles stop at 16384 rows (batch 9 - 16) / 32768 (to 8)
         # Q2_K: dot4 to batch 4 (2 with few rows), streamed to 16 and from 33, the LDS-tile kernel in between
         assert [L.ggq_mmq_route(10, b, k, n) for b in (2, 3, 4, 5, 16, 17, 32, 33, 128)] == \
             [DOT4, DOT4 if 8192 <= n <= 12288 else STREAM, DOT4 if 8192 <= n <= 12288 else STREAM, STREAM, STREAM, LDS_TILE, LDS_TILE, STREAM, STREAM]
@@ -109,6 +110,9 @@ def test_mmq_routing_table():
                     (16384, STREAM), (16416, T16), (28672, STREAM)):
         assert L.ggq_mmq_route(Q4_K, 32, 4096, n) == want and L.ggq_mmq_route(Q5_K, 32, 8192, n) == want, n
         assert L.ggq_mmq_route(Q4_K, 16, 4096, n) == T16
+    assert [L.ggq_mmq_route(Q6_K, 8, 4096, n) for n in (16384, 32768, 32769, 128256)] == [T16, T16, DOT4, DOT4]
+    assert [L.ggq_mmq_route(Q6_K, 16, 4096, n) for n in (16384, 16385, 128256)] == [T16, LDS_TILE, LDS_TILE]
+    assert L.ggq_mmq_route(Q8_0, 8, 4096, 128256) == T16 and L.ggq_mmq_route(Q5_K, 16, 4096, 128256) == T16
     # invalid inputs
     assert L.ggq_mmq_route(1, 8, 4096, 64) == NONE and L.ggq_mmq_route(Q4_K, 0, 4096, 64) == NONE
     assert L.ggq_mmq_route(20, 8, 4096, 64) == NONE   # IQ4_NL: no GEMM
