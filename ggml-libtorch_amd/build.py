@@ -55,7 +55,8 @@ def _stale(target, deps):
 
 def _common_deps():
     return [os.path.join(INCLUDE, "ggq.h"), os.path.join(CSRC, "hip", "ggq_common.h"),
-            os.path.join(CSRC, "hip", "mmq_unpack.h"), os.path.abspath(__file__)]
+            os.path.join(CSRC, "hip", "mmq_unpack.h"), os.path.join(CSRC, "hip", "iq_common.h"),
+            os.path.join(CSRC, "hip", "iq_tables.h"), os.path.abspath(__file__)]
 
 
 def build_hip(force=False, verbose=False):

@@ -46,7 +46,9 @@ extern "C" int ggq_peer_write_2d(void* dst, int64_t dst_pitch, const void* src, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Device-side hand-off (no host barrier, no stream drain, graph-capturable):
+// Device-side hand-off (no host barrier, no stream drain; NOT replayable from a captured graph: `generation`, the buffer
+// parity and the dst / flag pointers are host-computed kernel arguments, so a replay would wait for a generation that has
+// already been published and return at once — enqueue the pair eagerly, once per gather):
 //   ggq_peer_scatter  one kernel: copies the rank's [rows x row_bytes] slab into slot `rank` of every peer's buffer with
 //                     plain 16-byte stores, then — every storing wave drained (s_waitcnt vmcnt(0)), workgroup barrier, one
 //                     lane's SYSTEM-scope release fence — counts the workgroup in; the workgroup that arrives last

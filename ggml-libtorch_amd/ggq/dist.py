@@ -101,7 +101,9 @@ class PeerSlabGather:
     slot `rank` of each peer's buffer (device-to-device stores that cross xGMI when the ranks own different GPUs) and
     publishes a generation number into the peers' flag words once every storing workgroup has released its stores at
     system scope, followed by one tiny kernel that waits for the peers' flags (ggq_peer_scatter / ggq_peer_wait).  No
-    stream drain, no host barrier, no RCCL; the pair can be captured in a HIP graph.
+    stream drain, no host barrier, no RCCL.  NOT for HIP-graph replay: the generation number and the buffer parity are host-side
+    state passed as kernel arguments, so a replayed wait would return at once on the previous generation (stale slabs) —
+    call gather() / matmul_gather() eagerly, once per gather.
 
     Same interface as SlabGather: the matmul writes the rank's slab into `local` (out= / ldy), `gather()` makes `buf`
     ([P, batch, rows]) complete for everything enqueued behind it on the stream, `batch_major()` is the [batch, N] copy.
@@ -123,8 +125,8 @@ class PeerSlabGather:
         self.rank = dist.get_rank(group)
         if n_rows % self.world:
             raise ValueError("PeerSlabGather needs equal shards (n_rows % world_size == 0)")
-        if self.world > 9:
-            raise ValueError("PeerSlabGather: at most 8 peers")
+        if self.world > 8:   # ggq_mul_mat_q_gather / ggq_peer_scatter take at most 8 destinations (own slot + 7 peers)
+            raise ValueError("PeerSlabGather: at most 8 ranks")
         self.batch, self.rows = batch, n_rows // self.world
         esz = torch.empty((), dtype=dtype).element_size()
         if (self.rows * esz) % 16:
@@ -212,6 +214,16 @@ class PeerSlabGather:
         from . import lib as ggqlib
         L = self.L
         t = int(quant_type)
+        if x.dim() != 2 or x.shape[0] != self.batch:
+            raise ValueError(f"matmul_gather: x must be [{self.batch}, k], got {tuple(x.shape)}")
+        if w.dim() != 2 or w.shape[0] != self.rows or w.dtype != torch.uint8:
+            raise ValueError(f"matmul_gather: w must be this rank's uint8 [{self.rows}, row_bytes] shard, got {tuple(w.shape)} {w.dtype}")
+        if x.device != self._mem.device or w.device != self._mem.device:
+            raise ValueError("matmul_gather: x and w must live on the gather buffer's device")
+        if not (x.is_contiguous() and w.is_contiguous()):
+            raise ValueError("matmul_gather: x and w must be contiguous")
+        if x.dtype != self._bufs[0].dtype:
+            raise ValueError("matmul_gather: x must have the gather buffer's dtype (the slab is written in x's dtype)")
         k = x.shape[1]
         if scratch is None:
             scratch = torch.empty(int(L.ggq_mmq_scratch_bytes(self.batch, k)), dtype=torch.uint8, device=x.device)
@@ -238,7 +250,9 @@ class PeerSlabGather:
         return None
 
     def status(self) -> int:
-        """0, or 1 if a ggq_peer_wait gave up on a peer (synchronises the device)"""
+        """0, or 1 if a ggq_peer_wait gave up on a peer after its 2-second limit (synchronises the device).  The wait kernel
+        cannot stop the stream: work enqueued behind a timed-out wait has consumed incomplete slabs, so poll this before
+        trusting results whenever a peer may legitimately stall that long; close() / the context manager check it and raise."""
         return int(self._mem[self._flags_off + 2 * 64 * 4 + 64:self._flags_off + 2 * 64 * 4 + 68].view(torch.int32).item())
 
     def batch_major(self) -> torch.Tensor:
@@ -250,12 +264,15 @@ class PeerSlabGather:
             return
         self._closed = True
         torch.cuda.synchronize(self._mem.device)
+        timed_out = self.status() != 0
         dist.barrier(group=self.group)
         rcs = [self.L.ggq_peer_close(base, self._peer_off[p]) for p, base in list(self._peer_ptr.items())]
         self._peer_ptr.clear()
         dist.barrier(group=self.group)
         if any(rc != 0 for rc in rcs):
             raise RuntimeError(f"ggq_peer_close failed: {rcs}")
+        if timed_out:   # raised AFTER the collective part, so the ranks stay in step
+            raise RuntimeError("PeerSlabGather: a ggq_peer_wait gave up on a peer (2 s): results gathered since then are incomplete")
 
     def __del__(self):
         # never collective from a finaliser: only drop the mappings if close() was skipped

@@ -130,7 +130,11 @@ int ggq_mul_mat_vec_q(const void* w, const void* x, void* y, int type, int dtype
 
 /* replaces ggml_mul_mat_a8 (HK/ggml/mmq.cu:180-255) = quantize_mmq_q8_1 ∘ mul_mat_q
  * (HK/ggml/mmq.cuh:1917-2031). x: [batch,k]; y: [batch,n_rows] row-major (ldy = n_rows);
- * scratch: >= ggq_mmq_scratch_bytes(batch,k) device bytes, 16-byte aligned. */
+ * scratch: >= ggq_mmq_scratch_bytes(batch,k) device bytes, 16-byte aligned.
+ * Reproducibility: the integer contraction is exact; the fp32 accumulation ORDER is fixed per (type, batch, k, n_rows) —
+ * repeated launches, row permutations and token permutations of one call are bit-identical — but the kernel and its K-slice
+ * count are chosen from the whole shape (ggq_mmq_route), so a row of a row-sharded matrix may differ from the same row of the
+ * unsharded one in the last fp32 rounding (within the 1e-3 canon, never beyond it). */
 int ggq_mul_mat_q(const void* w, const void* x, void* y, int type, int dtype,
                   int64_t batch, int64_t k, int64_t n_rows, void* scratch, void* stream);
 
@@ -249,7 +253,11 @@ int ggq_peer_import(const void* handle_64_bytes, int64_t offset, void** dev_ptr_
 int ggq_peer_close(void* dev_ptr, int64_t offset);
 int ggq_peer_write_2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t row_bytes,
                       int64_t rows, void* stream);
-/* Device-side hand-off of the gather (ABI 5; no host barrier, no stream drain, graph-capturable):
+/* Device-side hand-off of the gather (ABI 5; no host barrier, no stream drain).  NOT replayable from a captured HIP graph:
+ * `generation`, the buffer parity and the dst / flag pointers are host-computed arguments, so a replayed ggq_peer_wait would
+ * find its generation already published and return at once (stale slabs, no error).  Enqueue the pair eagerly per gather.
+ * The 2-second give-up of ggq_peer_wait only sets *status: poll it (PeerSlabGather.status(), checked by close()) before
+ * trusting results produced behind a wait that may have timed out.
  * ggq_peer_scatter: one kernel stores the rank's [rows x row_bytes] slab into `dsts[0..n_dst)` (slot `rank` of each peer's
  *   buffer, mapped with ggq_peer_import; pitches in bytes, 16-byte multiples) and, once every workgroup has drained and
  *   released its stores at system scope, writes `generation` into `flags[d]` (a 4-byte word in peer d's memory, one per

@@ -143,7 +143,9 @@ def test_op_errors(ops):
     with pytest.raises(RuntimeError):
         ops.ggml_mul_mat_a8(w, torch.zeros((2, 256), dtype=torch.float16, device="cuda"), 20, 4)
     with pytest.raises(RuntimeError):
-        ops.ggml_dequantize(w, 21, 4, 256)  # IQ2_S: not built
+        ops.ggml_dequantize(w, 24, 4, 256)  # id 24 (GGML_TYPE_I8) is no quantised weight format: refused, not dispatched to a null pointer
+    with pytest.raises(RuntimeError):
+        ops.ggml_dequantize(w, 21, 4, 256)  # IQ3_S is built, but 4 x 18 bytes are not 4 rows of 110-byte super-blocks: byte-count check
 
 
 @pytest.mark.parametrize("quant_type", [GGMLType.Q4_K, GGMLType.Q8_0, GGMLType.Q6_K, GGMLType.Q4_0], ids=lambda t: t.name)

@@ -156,3 +156,42 @@ def test_waitcnt_placement_of_the_headline_and_mid_batch_kernels():
     assert " 0 unwaited register uses" in r.stdout and "kernels checked" in r.stdout
     n = int(r.stdout.strip().split("\n")[-1].split(" kernels checked")[0])
     assert n >= 5, r.stdout[-500:]
+
+
+def test_bench_line_is_compact_and_round_trips():
+    """bench.py's last stdout line is what the driver parses: BENCH_r03.json had `parsed: null` because the line had grown to
+    21.7 KB.  Serialise a line with EVERY key populated (round 3's full record as the detail side) and require a bounded,
+    single-line JSON object that round-trips and still carries the contract keys, `roofline` and `cpu_baseline`."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config")
+    out = {k: full[k] for k in contract}
+    out.update({k: full[k] for k in ("pct_hbm_roofline", "ms_per_step_gpu_events", "value_gpu_events", "value_warm")})
+    out["roofline"] = {"bound": "hbm", "achieved": 1102.53, "peak": 8000.0, "unit": "GB/s", "frac": 0.1378, "traffic": 33207632,
+                       "kernel": bench.ROOFLINE_KERNEL, "avg_launch_us": 26.511, "cache_state": "cold", "warm_avg_launch_us": 23.043,
+                       "warm_frac": 0.1586, "algorithmic_bytes_per_launch": 29229056, "frac_int8_mfma_peak": 0.0871}
+    detail = {k: full[k] for k in ("extra", "strong_scaling_config5", "cpu_baseline", "cpu_config1_q4_0_dequant_4096x4096",
+                                   "cpu_torch_matmul_on_dequantised")}
+    detail["large_batch"] = {f"mmq_{n}_batch{b}": {"us": 123.456, "speedup_vs_dequantize_plus_rocblas": 1.234}
+                             for n in ("Q4_K", "Q8_0", "Q6_K") for b in (512, 2048, 4096)}
+    line = bench.compact_line(out, detail)
+    assert "\n" not in line and len(line.encode()) <= bench.MAX_LINE_BYTES <= 8192
+    back = json.loads(line)
+    for k in contract:
+        assert back[k] == out[k], k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"]
+    assert back["roofline"]["bound"] in ("hbm", "mfma")
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"]
+    assert back["cpu_baseline"]["kind"] in ("port", "reference")
+    assert "extra" not in back and "strong_scaling_config5" not in back
+    assert back["summary_us"]["mmq_Q8_0_b128"]["us_cold"] == full["extra"]["mmq_Q8_0_batch128"]["cold"]["us"]
+    # an over-long config must still give a parseable line (optional parts are dropped, never the contract keys)
+    out2 = dict(out, config=dict(out["config"], workload="x" * 1500))
+    assert len(bench.compact_line(out2, detail)) <= bench.MAX_LINE_BYTES
