@@ -23,13 +23,13 @@ INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 ARCH = "gfx950"
 EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX")
 
-HIP_SOURCES = ["dequant", "quantize", "mmvq", "mmq", "mmq_t16", "peer"]
+HIP_SOURCES = ["dequant", "quantize", "mmvq", "mmq", "mmq_t16", "mmq_x64", "peer"]
 TRAITS_SRC = os.path.join(CSRC, "core", "traits.cpp")
 # No implicit fused-multiply-add contraction anywhere: the fp16 dequantise sequence and the Q8_1
 # quantiser must round after every operation exactly like the reference's intrinsics, and in the
 # matmul kernels contraction made the rounding of an output depend on which accumulator register
 # (i.e. which tile row) it landed in.  FMAs are written explicitly (__builtin_fmaf) where wanted.
-NO_CONTRACT = {"dequant", "quantize", "mmvq", "mmq", "mmq_t16"}
+NO_CONTRACT = {"dequant", "quantize", "mmvq", "mmq", "mmq_t16", "mmq_x64"}
 
 
 def _hipcc():
@@ -56,7 +56,7 @@ def _stale(target, deps):
 def _common_deps():
     return [os.path.join(INCLUDE, "ggq.h"), os.path.join(CSRC, "hip", "ggq_common.h"),
             os.path.join(CSRC, "hip", "mmq_unpack.h"), os.path.join(CSRC, "hip", "iq_common.h"),
-            os.path.join(CSRC, "hip", "iq_tables.h"), os.path.abspath(__file__)]
+            os.path.join(CSRC, "hip", "iq_tables.h"), os.path.join(CSRC, "hip", "mmq_x64_loops.inc"), os.path.abspath(__file__)]
 
 
 def build_hip(force=False, verbose=False):

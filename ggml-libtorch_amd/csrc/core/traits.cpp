@@ -92,7 +92,24 @@ extern "C" size_t ggq_mmvq_scratch_bytes(int64_t k) {
 }
 extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
   // whole 32-token tiles: the fragment-major layout (ggq_quantize_q8_1_tiled) addresses tiles
-  return (size_t)((batch + 31) / 32 * 32) * (size_t)(ggq_mmq_padded_k(k) / 32 * 36);
+  const size_t tiled = (size_t)((batch + 31) / 32 * 32) * (size_t)(ggq_mmq_padded_k(k) / 32 * 36);
+  // the x64 layout (ggq_quantize_q8_1_x64): 10240-byte records per (256 elements, 32 tokens), token tiles in pairs
+  const size_t x64 = k % 256 ? 0 : (size_t)((batch + 63) / 64 * 2) * (size_t)(k / 256) * 10240;
+  return tiled > x64 ? tiled : x64;
+}
+
+// the 64 x 64 wave-tile kernel (csrc/hip/mmq_x64.hip)
+extern "C" int ggq_mmq_x64_type_supported(int type) {
+  switch (type) {
+    case GGQ_TYPE_Q4_K: return 1;
+    default: return 0;
+  }
+}
+extern "C" int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch) {
+  if (!ggq_mmq_x64_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
+  if ((uint64_t)((batch + 63) / 64 * 2) * (uint64_t)(k / 256) * 10240 >= (1ull << 32)) return 0;   // 32-bit byte offsets into the scratch
+  if ((uint64_t)ggq_row_bytes(type, k) * 64 >= (1ull << 32)) return 0;                             // ... and inside a 64-row weight tile
+  return 1;
 }
 
 // ---- which kernel ggq_mul_mat_q runs: the role of the reference's tile heuristic (mul_mat_q_case / get_mmq_x_max_host,

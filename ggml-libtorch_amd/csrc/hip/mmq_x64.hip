@@ -1,0 +1,197 @@
+// mmq_x64.hip — quantised GEMM  Y[B,N] = X[B,K] (Q8_1) · W[N,K]^T for batches from 33 tokens up: 64-row x 64-token wave tiles,
+// K loop in hand-scheduled gfx950 assembly (generated: scripts/gen_mmq_x64.py -> mmq_x64_loops.inc).
+//
+// Replaces, for the formats it serves, mul_mat_q's large-tile instances (HK/ggml/mmq.cuh:1917-1986 with mmq_x = 64 ... 128,
+// kernel_instances/mmq_kernel.cuh:21-32) and their vec_dot_*_q8_1_mma bodies (mmq.cuh:1247-1363 for Q4_K).  Same numerical contract as
+// mmq.hip ("MMQ canon"): exact integer contraction per 32-group, fp16 d8 / s8 for the need_sum formats, s8 (not d8·Σq8)
+// in the Q4_K min term; the fp32 accumulation order is this kernel's.
+//
+// Structure:
+//   workgroup = 4 waves = 4 K-slices of one unit (64 weight rows x 64 tokens); no workgroup barrier in the K loop;
+//   wave tile = 2 x 2 MFMA tiles (v_mfma_i32_32x32x32_i8), lane = weight row, accumulator register = token: the row scale d·sc is a lane
+//     scalar decoded from the row's own header, the token scales come from the scratch as packed fp16 and are read in place by
+//     v_fma_mix_f32 — no scale ever crosses lanes;
+//   two MFMA result sets: the 8 + 16 FMAs of tile n-1 are issued under the MFMA of tile n, unpack / decode / address work sits in
+//     the MFMA's issue shadow (scripts/ubench_tile.hip: 50-52 ns per tile per SIMD against 100+ in mmq_stream_kernel);
+//   weights: raw super-block bytes, each byte once, row-major by LDS-DMA into a wave-private two-stage ring; the ring's rows are
+//     144 bytes apart = an odd number of 16-byte units: every ds_read_b128 of the loop is conflict-free;
+//   activations: the x64 scratch layout (quantize.hip LAYOUT 5): per (super-block, 32-token tile) 8 fragments of 1 KB in lane
+//     order, the 32 token scales of every group as fp16 in accumulator-register order, the s8 operand of the min-term MFMA;
+//   min term Σ_g (-dmin·m_g)[row]·s8_g[token]: ONE v_mfma_f32_32x32x16_f16 per super-block and tile (exact hi + lo fp16 split, as in
+//     mmq_stream_kernel), rows with |dmin| > 1024 through a 2^-8-scaled cold pass;
+//   K-slice partial sums meet once in LDS and are added in slice order; the write-back reads them back transposed, so that a
+//     thread stores 16 consecutive rows of one token (32 contiguous bytes, a token's 64 rows = one 128-byte line).
+#include "ggq_common.h"
+
+namespace ggq {
+
+typedef float v32f __attribute__((ext_vector_type(32)));
+
+#ifndef GGQ_X64_LOOPS_INC
+#define GGQ_X64_LOOPS_INC "mmq_x64_loops.inc"   // (scripts/build_variant.sh points experiments at another generated file)
+#endif
+#include GGQ_X64_LOOPS_INC
+
+struct X64Epilogue { int kind; const void* aux; };
+
+template <int DT>
+__device__ __forceinline__ float x64_apply_epilogue(float v, int epi, const void* aux, int64_t yi, int row) {
+  if (epi == GGQ_EPI_BIAS) return v + Elem<DT>::ld(aux, row);
+  if (epi == GGQ_EPI_SILU_MUL) {
+    const float g = Elem<DT>::ld(aux, yi);
+    return v * (g / (1.0f + expf(-g)));
+  }
+  return v;
+}
+
+constexpr int X64_REC = 10240;          // bytes of one (super-block, 32-token tile) record of the x64 scratch layout
+constexpr int X64_STAGE = 64 * 144;     // Q4_K: one ring stage = 64 rows x one super-block
+constexpr int X64_LDS = 4 * 2 * X64_STAGE;   // four wave-private rings; the K-slice reduction (64 KB) aliases them
+
+template <int T, int DT>
+__global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
+                                                         void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
+                                                         int n_tok_tiles, int n_units, int per_xcd, int epi,
+                                                         const void* __restrict__ aux) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
+  if (unit >= n_units) return;
+  const int row_tile = unit / n_tok_tiles, tok_tile = unit % n_tok_tiles;
+  const int n0 = row_tile * 64, t0 = tok_tile * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int n_sb = k / 256;
+  const int sb_begin = (int)((int64_t)ks * n_sb / 4), sb_end = (int)((int64_t)(ks + 1) * n_sb / 4);
+  const uint32_t row_bytes = (uint32_t)n_sb * Fmt<T>::BS;
+  const int valid_rows = min(64, n_rows - n0);
+
+  v32f acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+
+  if (sb_begin < sb_end) {   // wave-uniform
+    v16i magic;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) magic[i] = 0x4B400000;
+    // weights: the tile's valid rows only — rows past the tensor read as zeros (d = 0: they contribute nothing and are never stored)
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(w + (int64_t)n0 * row_bytes), 0, (int)((uint32_t)valid_rows * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q8, 0, (int)0xFFFFFFFFu, 0x00020000);
+    const uint32_t n_tt32 = 2u * (uint32_t)n_tok_tiles;                  // 32-token records per super-block
+    const uint32_t sbstride = n_tt32 * X64_REC;
+    const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
+    const uint32_t ring = (uint32_t)(uintptr_t)lds + (uint32_t)ks * (2 * X64_STAGE);
+    const uint32_t hoff = 16u + 16u * (uint32_t)h;
+    x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, (uint32_t)h * 32u, ring + (uint32_t)r * 144u + hoff, hoff, (uint32_t)lane,
+                 wrsrc, arsrc, ring, (uint32_t)(sb_end - sb_begin), sbstride, (uint32_t)sb_begin * 144u, row_bytes - 144u, f0,
+                 f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+  }
+
+  // ---- K-slice reduction: red[slice][tile][register][lane]; the rings are dead once every wave is past its last ds_read ----
+  __syncthreads();
+  float* red = (float*)lds;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    red[((ks * 4 + (i >> 4)) * 16 + (i & 15)) * 64 + lane] = acc0[i];
+    red[((ks * 4 + 2 + (i >> 4)) * 16 + (i & 15)) * 64 + lane] = acc1[i];
+  }
+  __syncthreads();
+  // thread -> (token tl64 of the unit, 16 consecutive rows): lane (row r, half h) of tile (rt, tt) holds token 32 tt + 8 (i >> 2) + 4 h + (i & 3)
+  // of row 32 rt + r in register i, so four consecutive rows of one token are four consecutive floats of red[]
+  const int tl64 = tid >> 2, rb = (tid & 3) * 16;
+  const int t = t0 + tl64;
+  if (t >= batch) return;
+  const int tt = tl64 >> 5, tl = tl64 & 31;
+  const int i_reg = 4 * (tl >> 3) + (tl & 3), hh = (tl >> 2) & 1;
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int R = rb + 4 * j, rt = R >> 5, rr = R & 31;
+    v4f s = *(const v4f*)(red + (((0 * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
+#pragma unroll
+    for (int sl = 1; sl < 4; ++sl) {
+      const v4f p = *(const v4f*)(red + (((sl * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
+      s += p;   // fixed slice order ((0 + 1) + 2) + 3
+    }
+    v[4 * j] = s[0]; v[4 * j + 1] = s[1]; v[4 * j + 2] = s[2]; v[4 * j + 3] = s[3];
+  }
+  const int row0 = n0 + rb;
+  const int64_t yi0 = (int64_t)t * ldy + row0;
+  if (epi != GGQ_EPI_NONE) {   // wave-uniform
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (row0 + e < n_rows) v[e] = x64_apply_epilogue<DT>(v[e], epi, aux, yi0 + e, row0 + e);
+  }
+  const bool vec_ok = DT != GGQ_F32 && (ldy & 7) == 0 && ((uintptr_t)y & 15) == 0 && row0 + 16 <= n_rows;
+  if (vec_ok) {
+    uint32_t pk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint16_t lo, hi;
+      if (DT == GGQ_F16) {
+        lo = __builtin_bit_cast(uint16_t, (_Float16)v[2 * e]);
+        hi = __builtin_bit_cast(uint16_t, (_Float16)v[2 * e + 1]);
+      } else {
+        lo = Elem<GGQ_BF16>::cvt(v[2 * e]);
+        hi = Elem<GGQ_BF16>::cvt(v[2 * e + 1]);
+      }
+      pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+    v4i* dst = (v4i*)((uint16_t*)y + yi0);
+    dst[0] = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+    dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (row0 + e < n_rows) Elem<DT>::st(y, yi0 + e, v[e]);
+  }
+}
+
+template <int T, int DT>
+static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
+                      X64Epilogue ep) {
+  const int64_t n_tok_tiles = (batch + 63) / 64;
+  const int64_t n_units = ((n + 63) / 64) * n_tok_tiles;
+  if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
+  auto kern = mmq_x64_kernel<T, DT>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64_LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
+  const int64_t per_xcd = (n_units + 7) / 8;
+  GGQ_HIP_PRE_LAUNCH();
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), X64_LDS, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
+                     (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
+}
+
+template <int T>
+static int launch_x64_dt(const void* w, const void* q8, void* y, int dt, int64_t batch, int64_t k, int64_t n, int64_t ldy,
+                         hipStream_t s, X64Epilogue ep) {
+  switch (dt) {
+    case GGQ_F32: return launch_x64<T, GGQ_F32>(w, q8, y, batch, k, n, ldy, s, ep);
+    case GGQ_F16: return launch_x64<T, GGQ_F16>(w, q8, y, batch, k, n, ldy, s, ep);
+    case GGQ_BF16: return launch_x64<T, GGQ_BF16>(w, q8, y, batch, k, n, ldy, s, ep);
+    default: return GGQ_ERR_DTYPE;
+  }
+}
+
+}  // namespace ggq
+
+extern "C" int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
+                                 int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream) {
+  using namespace ggq;
+  if (epilogue < GGQ_EPI_NONE || epilogue > GGQ_EPI_SILU_MUL || (epilogue != GGQ_EPI_NONE && !aux)) return GGQ_ERR_ARG;
+  if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
+  if (!ggq_mmq_x64_type_supported(type)) return GGQ_ERR_TYPE;
+  if (k % 256 || n_rows > 0x7fffffffLL - 64) return GGQ_ERR_SHAPE;
+  if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (n_rows == 0 || batch == 0) return GGQ_OK;
+  if (!ggq_mmq_x64_supported(type, k, batch)) return GGQ_ERR_SHAPE;
+  if (!w || !q || !y) return GGQ_ERR_ARG;
+  if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
+  const X64Epilogue ep{epilogue, aux};
+  switch (type) {
+    case GGQ_TYPE_Q4_K: return launch_x64_dt<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
+    default: return GGQ_ERR_TYPE;
+  }
+}

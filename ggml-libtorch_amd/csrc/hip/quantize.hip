@@ -39,6 +39,13 @@ __device__ __forceinline__ void load4(const void* x, int64_t base, int64_t ix, i
 // table of 16-element runs, or GGQ_T16_RUN8 for the 32-element nibble blocks (Q4_0 Q4_1 Q5_0 Q5_1), whose weight lane
 // (K-chunk c of MFMA f) holds 8 raw bytes = elements 8 h .. 8 h + 7 (low nibbles) and 16 + 8 h .. (high nibbles) of block
 // 2 f + (c >> 1), h = c & 1: the slot is those two 8-element runs, low-nibble run first.
+// LAYOUT 5: the x64 layout (mmq_x64.hip): per (ix/256, token/32) a 10240-byte record
+//           { int8 frag[8 groups][2 K-halves][32 tokens][16]                        8192 bytes, one MFMA operand fragment = 1 KB in lane order
+//             d8[8 groups][2 halves h][4 quads qd][4 e]                              token 8 qd + 4 h + e: accumulator-register order of lane half h;
+//                                                                                    fp16 (64 bytes per group) for the need_sum formats, else fp32 (128)
+//             fp16 s8[2 kh][32 tokens][8] = s8(4kh) s8(4kh+1) s8(4kh) s8(4kh+1) s8(4kh+2) s8(4kh+3) s8(4kh+2) s8(4kh+3)   at byte 9216: the
+//                                                                                    operand of the min-term MFMA (need_sum formats) }
+//           records of a 256-element K step are contiguous over the token tiles, whose count is rounded up to even (64-token units).
 #define GGQ_T16_RUN8 (~0ull)
 __device__ __forceinline__ void t16_slot(uint64_t inv, int e256, int& slot, int& byte) {
   if (inv == GGQ_T16_RUN8) {
@@ -105,6 +112,25 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
       const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
       const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
       *(uint32_t*)blk = (uint32_t)hd | ((uint32_t)hs << 16);
+    }
+  } else if (LAYOUT == 5) {
+    const int64_t n_tt = ((batch + 63) >> 6) << 1;
+    uint8_t* rec = q + ((g >> 3) * n_tt + (t >> 5)) * 10240;
+    const int g8 = (int)(g & 7), tl = (int)(t & 31);
+    *(uint32_t*)(rec + g8 * 1024 + (e >> 4) * 512 + tl * 16 + (e & 15)) = packed;
+    if (e == 0) {
+      const int idx = ((tl >> 2) & 1) * 16 + (tl >> 3) * 4 + (tl & 3);   // [h][qd][e]
+      if (NEED_SUM) {
+        const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+        const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
+        *(uint16_t*)(rec + 8192 + g8 * 64 + idx * 2) = hd;
+        uint16_t* s8 = (uint16_t*)(rec + 9216 + ((g8 >> 2) * 32 + tl) * 16);
+        const int j = g8 & 3, p0 = (j >> 1) * 4 + (j & 1);
+        s8[p0] = hs;
+        s8[p0 + 2] = hs;
+      } else {
+        *(float*)(rec + 8192 + g8 * 128 + idx * 4) = d;
+      }
     }
   } else if (LAYOUT == 4) {
     // batch <= 8: per ix/256 a 2304-byte tile { int8 frag[4][4 K-chunks][8 tokens][16]; ds[2 halves][2 token quads][4 groups][4 tokens] }
@@ -245,6 +271,20 @@ extern "C" int ggq_quantize_q8_1_t16(const void* x, int x_dtype, void* q, int64_
   if (ggq_mmq_need_sum(type))
     return launch_quant<3, true>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream, inv);
   return launch_quant<3, false>(x, x_dtype, q, batch, k, padded, (hipStream_t)stream, inv);
+}
+
+extern "C" int ggq_quantize_q8_1_x64(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,
+                                     int type, void* stream) {
+  using namespace ggq;
+  if (batch < 0 || k <= 0) return GGQ_ERR_ARG;
+  if (x_dtype < GGQ_F32 || x_dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (!ggq_mmq_x64_type_supported(type)) return GGQ_ERR_TYPE;
+  if (batch == 0) return GGQ_OK;
+  if (!ggq_mmq_x64_supported(type, k, batch)) return GGQ_ERR_SHAPE;
+  if (!x || !q) return GGQ_ERR_ARG;
+  if ((uintptr_t)q & 15) return GGQ_ERR_ALIGN;
+  if (ggq_mmq_need_sum(type)) return launch_quant<5, true>(x, x_dtype, q, batch, k, k, (hipStream_t)stream);
+  return launch_quant<5, false>(x, x_dtype, q, batch, k, k, (hipStream_t)stream);
 }
 
 extern "C" int ggq_quantize_q8_1(const void* x, int x_dtype, void* q, int64_t batch, int64_t k,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 7   /* 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather; 7: ggq_mmq_stream_unit_tokens */
+#define GGQ_ABI_VERSION 8   /* 8: ggq_*_x64 (64 x 64 wave tiles, batches from 33 tokens), GGQ_MMQ_ROUTE_X64; 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather; 7: ggq_mmq_stream_unit_tokens */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -198,12 +198,26 @@ int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype
                       int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                       int epilogue, const void* aux, void* stream);
 
+/* 64-row x 64-token wave tiles for the batches from 33 tokens up (round 4; the role of mul_mat_q's mmq_x = 64 ... 128 instances,
+ * HK/ggml/kernel_instances/mmq_kernel.cuh:21-32 + mmq.cuh:1917-1986, at the reference benchmark's own batch sizes,
+ * benchmarks/benchmark_mmq.py:152).  K loop in hand-scheduled gfx950 assembly (scripts/gen_mmq_x64.py).  The scratch ("x64 layout",
+ * ggq_quantize_q8_1_x64) holds the same Q8_1 values as ggq_quantize_q8_1_mmq, regrouped per (k/256, token/32) into 10240-byte records
+ * { int8 frag[8 groups][2 K-halves][32 tokens][16];  d8[8 groups][32 tokens] as fp16 (need_sum formats) or fp32, tokens in
+ * accumulator-register order;  fp16 s8 operand of the min-term MFMA [2][32 tokens][8] }, token tiles padded to a multiple of 64
+ * tokens.  q: >= ggq_mmq_scratch_bytes(batch, k) bytes, 16-byte aligned.  Formats: ggq_mmq_x64_type_supported(); k a multiple of 256,
+ * scratch below 4 GiB (ggq_mmq_x64_supported; GGQ_ERR_SHAPE otherwise).  Epilogue arguments as ggq_mul_mat_q_pretiled_epi. */
+int ggq_mmq_x64_type_supported(int type);
+int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch);
+int ggq_quantize_q8_1_x64(const void* x, int x_dtype, void* q, int64_t batch, int64_t k, int type, void* stream);
+int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
+                      int64_t ldy, int epilogue, const void* aux, void* stream);
+
 /* Which kernel ggq_mul_mat_q / _ld / _epi run for a (type, batch, k, n_rows): the role of the reference's tile
  * heuristic (mul_mat_q_case + get_mmq_x_max_host, HK/ggml/kernel_instances/mmq_kernel.cuh:21-32, mmq.cuh:155-164).
  * Host-only, no GPU needed.  DOT4 = batch <= 8 GEMV-like kernel, LDS_TILE = barrier-coupled kernel on the reference
  * layout, STREAM = 32 / 64-token MFMA units on the fragment-major scratch, T16 = 16-token tiles (ggq_mul_mat_q_t16). */
 enum ggq_mmq_route_id { GGQ_MMQ_ROUTE_NONE = 0, GGQ_MMQ_ROUTE_DOT4 = 1, GGQ_MMQ_ROUTE_LDS_TILE = 2, GGQ_MMQ_ROUTE_STREAM = 3,
-                        GGQ_MMQ_ROUTE_T16 = 4 };
+                        GGQ_MMQ_ROUTE_T16 = 4, GGQ_MMQ_ROUTE_X64 = 5 };
 int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows);
 /* Tokens per workgroup unit (32 or 64) the STREAM route uses for a (type, batch, n_rows): the other half of the tile heuristic's role
  * (mmq_x of mul_mat_q_case, HK/ggml/kernel_instances/mmq_kernel.cuh:21-32).  Host-only. */

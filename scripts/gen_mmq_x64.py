@@ -1,0 +1,459 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K loop of the 64 x 64 wave-tile GEMM (csrc/hip/mmq_x64.hip): gfx950 assembly with PHYSICAL
+registers, one inline-asm statement per weight format, written to csrc/hip/mmq_x64_loops.inc.
+
+Why generated assembly: the loop is bound by the SIMD's own vector + matrix issue — two exact FMAs per (row, token, 32-group) triple
+beside one int8 MFMA per 32 x 32 x 32 tile (reference role: vec_dot_*_q8_1_mma, HK/ggml/mmq.cuh:913-1737) — and hipcc neither keeps two
+MFMA result sets in flight nor leaves prefetches where they are put.  Here every instruction is placed:
+    MFMA(tile n)  ->  plain vector fillers in the MFMA's issue shadow (unpack, scale decode, addresses, loads)  ->  the FMAs of tile n-1
+scripts/ubench_tile.hip measured that stream at 50-52 ns per tile per SIMD (two waves per SIMD) against 100+ in the round-3 kernel.
+
+Wave tile: 64 weight rows x 64 tokens (2 x 2 MFMA tiles), lane = weight row, accumulator register = token:
+    first stage   t   = fma(12582912 + C, dw, -12582912 dw)   = RN(C * dw) exactly (dw = d * sc has <= 19 significant bits)
+    second stage  acc = fma(t, d8[token], acc)                  d8 fp16 in place (v_fma_mix_f32) for the need_sum formats
+Weights: raw super-block bytes, row-major, by LDS-DMA into a wave-private two-stage ring (one stage = one 256-element K step of 64 rows);
+activations + their scales straight from the x64 scratch layout (quantize.hip LAYOUT 5) into registers, one 32-group ahead.
+
+usage: python scripts/gen_mmq_x64.py [--list]     (rewrites ggml-libtorch_amd/csrc/hip/mmq_x64_loops.inc)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "ggml-libtorch_amd", "csrc", "hip", "mmq_x64_loops.inc")
+
+# ------------------------------------------------------------------------------------------------ register map (Q4_K)
+ACC = 0            # v[0:63]    accumulators, tile ti = 2 tt + rt at 16 ti
+CSET = (64, 80)    # two MFMA result sets
+MAGICV = 96        # v[96:111]  0x4B400000 (input)
+RAW = (112, 116)   # raw quant bytes of the current pair, per row tile
+WOP = (120, 124)   # int8 MFMA operand of the current group, per row tile
+ACT = ((128, 132), (136, 140))          # [group parity][tt]
+D8 = ((144, 152), (160, 168))           # [group parity][tt], 8 registers each = 16 fp16 token scales
+DWNM = (176, 180)  # per row tile: dw_even, dw_odd, nm_even, nm_odd
+HDR = (184, 190)   # per row tile: sc_lo, sc_hi, m_lo, m_hi, d, dmin
+BMIN = (196, 200)  # per row tile: min-term operand (hi / lo split of -dmin * m), 4 registers
+S8 = (204, 208)    # per token tile: s8 operand, 4 registers
+V_LANE16, V_H32, V_LDSW0, V_HOFF, V_LANE = 212, 213, 214, 215, 216          # inputs
+V_LDSW, V_LDSWN, V_LDSHN = 217, 218, 219
+T_DW, T_WHI, T_DMA, T_HW, T_HD = 220, 222, 226, 228, 236                     # temporaries by task (T_HW: header words, 8; also bmin temps)
+N_VGPR = 238
+
+# SGPRs (physical; the C++ side binds its values to them)
+S_WRSRC, S_ARSRC = 36, 40          # s[36:39] weight tile descriptor, s[40:43] activation scratch descriptor
+S_LDS, S_NSB, S_SBSTRIDE, S_WK, S_RBD = 44, 45, 46, 47, 48     # S_RBD = row_bytes - bytes of a row in one stage
+S_F0, S_F1, S_D0, S_D1, S_S8 = 49, 50, 51, 52, 53               # running byte offsets into the scratch
+S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN = 54, 55, 56, 57, 58, 59
+S_NEGM, S_1024, S_MASK0F, S_HI = 60, 62, 63, 66                  # s[60:61] = -12582912.0f x 2; s[66:67] = lanes 32-63
+S_BIG, S_256 = 68, 70                                            # s[68:69] cold-path mask, s[70:71] = 256.0f x 2
+REC = 10240        # bytes of one (super-block, 32-token tile) record of the scratch
+ROWS = 64
+# experiment switches (scripts only; the shipped .inc is generated with the defaults)
+X_INPLACE = int(os.environ.get("X64_INPLACE", "1"))    # 0: the first stage writes a separate register set instead of the MFMA's
+X_NOPS = int(os.environ.get("X64_NOPS", "0"))          # s_nop wait states after every int8 MFMA
+TSET = 240
+X_NOMIN = int(os.environ.get("X64_NOMIN", "0"))        # 1: no min-term MFMA (wrong results; determinism experiments only)
+X_PLAIN2 = int(os.environ.get("X64_PLAIN2", "0"))      # 1: second stage as plain v_fma_f32 on the raw d8 dwords (wrong results; determinism experiments only)
+X_NODMA = int(os.environ.get("X64_NODMA", "0"))        # 1: no LDS-DMA inside the loop, every super-block re-reads stage 0 (wrong results; determinism experiments only)
+
+
+def vr(b, n=1):
+    if n > 1:
+        assert b % 2 == 0, b   # gfx950: 64-bit and wider VGPR tuples are even-aligned
+    return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
+
+
+def sr(b, n=1):
+    if n > 1:
+        assert b % 2 == 0, b
+    return f"s{b}" if n == 1 else f"s[{b}:{b + n - 1}]"
+
+
+class Asm:
+    """instruction list + in-order counters for vector memory (vmcnt) and LDS (lgkmcnt) operations"""
+
+    def __init__(self):
+        self.lines, self.vm, self.lg = [], [], []
+
+    def i(self, s):
+        self.lines.append(s)
+
+    def vmem(self, s, tag):
+        self.lines.append(s)
+        self.vm.append(tag)
+
+    def lds(self, s, tag):
+        self.lines.append(s)
+        self.lg.append(tag)
+
+    def _wait(self, q, tag, name, limit):
+        if tag not in q:
+            return q
+        idx = len(q) - 1 - q[::-1].index(tag)   # youngest operation with that tag
+        n = len(q) - 1 - idx
+        assert n <= limit, (name, n)
+        self.lines.append(f"s_waitcnt {name}({n})")
+        return q[idx + 1:]
+
+    def wait_vm(self, tag):
+        self.vm = self._wait(self.vm, tag, "vmcnt", 63)
+
+    def wait_lg(self, tag):
+        self.lg = self._wait(self.lg, tag, "lgkmcnt", 15)
+
+
+class Q4K:
+    name, type_id = "q4k", 12
+    BS = 144                 # bytes of a row in one stage (one super-block)
+    CPR, DIV = 9, 7282       # 16-byte chunks per row of a stage; c / CPR = (c * DIV) >> 16
+    N_DMA = 9                # LDS-DMA instructions per stage (64 rows x CPR chunks / 64 lanes)
+    QS_OFF = 16              # first quant byte inside the super-block
+    STAGE = ROWS * 144
+
+
+F = Q4K
+
+
+def mfma(a, g, ti):
+    rt, tt = ti & 1, ti >> 1
+    c = CSET[(4 * g + ti) & 1]
+    if ti == 0:
+        a.wait_vm(f"act0_{g & 1}")
+    if ti == 2:
+        a.wait_vm(f"act1_{g & 1}")
+    a.i(f"v_mfma_i32_32x32x32_i8 {vr(c, 16)}, {vr(ACT[g & 1][tt], 4)}, {vr(WOP[rt], 4)}, {vr(MAGICV, 16)}")
+    if X_NOPS:
+        a.i(f"s_nop {X_NOPS - 1}")
+
+
+def fma_block(a, g, ti):
+    """the two exact FMAs per triple of tile (g, ti); its MFMA was issued one tile ago"""
+    rt, tt = ti & 1, ti >> 1
+    c = CSET[(4 * g + ti) & 1]
+    p = g & 1
+    if ti in (0, 2):
+        a.wait_vm(f"d8_{tt}_{p}")
+    dw, nm = DWNM[rt], DWNM[rt] + 2
+    tdst = c if X_INPLACE else TSET
+    for j in range(0, 16, 2):
+        a.i(f"v_pk_fma_f32 {vr(tdst + j, 2)}, {vr(c + j, 2)}, {vr(dw, 2)}, {vr(nm, 2)} op_sel:[0,{p},{p}] op_sel_hi:[1,{p},{p}]")
+    acc = ACC + 16 * ti
+    d8 = D8[p][tt]
+    for i in range(16):
+        if X_PLAIN2:
+            a.i(f"v_fma_f32 {vr(acc + i)}, {vr(tdst + i)}, {vr(d8 + (i >> 1))}, {vr(acc + i)}")
+        else:
+            a.i(f"v_fma_mix_f32 {vr(acc + i)}, {vr(tdst + i)}, {vr(d8 + (i >> 1))}, {vr(acc + i)} op_sel:[0,{i & 1},0] op_sel_hi:[0,1,0]")
+
+
+def dw_prep(a, q, rt):
+    """row scales of groups 2q, 2q+1: dw = d * sc, nm = -12582912 * dw"""
+    sc = HDR[rt] + (q >> 1)
+    b0 = 2 * (q & 1)
+    a.i(f"v_cvt_f32_ubyte{b0} {vr(T_DW)}, {vr(sc)}")
+    a.i(f"v_cvt_f32_ubyte{b0 + 1} {vr(T_DW + 1)}, {vr(sc)}")
+    a.i(f"v_pk_mul_f32 {vr(DWNM[rt], 2)}, {vr(T_DW, 2)}, {vr(HDR[rt] + 4, 2)} op_sel_hi:[1,0]")
+    a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 2, 2)}, {vr(DWNM[rt], 2)}, {sr(S_NEGM, 2)}")
+
+
+def w_hi(a, rt):
+    for k in range(4):
+        a.i(f"v_lshrrev_b32 {vr(T_WHI + k)}, 4, {vr(RAW[rt] + k)}")
+    for k in range(4):
+        a.i(f"v_and_b32 {vr(WOP[rt] + k)}, {sr(S_MASK0F)}, {vr(T_WHI + k)}")
+
+
+def w_lo(a, rt):
+    a.wait_lg(f"raw{rt}")
+    for k in range(4):
+        a.i(f"v_and_b32 {vr(WOP[rt] + k)}, {sr(S_MASK0F)}, {vr(RAW[rt] + k)}")
+
+
+def raw_read(a, rt, q):
+    """raw nibble bytes of pair q (q = 4: pair 0 of the NEXT stage) of this lane's row: 16 bytes at QS_OFF + 32 q + 16 h"""
+    if q < 4:
+        a.lds(f"ds_read_b128 {vr(RAW[rt], 4)}, {vr(V_LDSW)} offset:{rt * 32 * F.BS + 32 * q}", f"raw{rt}")
+    else:
+        a.lds(f"ds_read_b128 {vr(RAW[rt], 4)}, {vr(V_LDSWN)} offset:{rt * 32 * F.BS}", f"raw{rt}")
+
+
+def act_loads(a, par):
+    """activation fragments of the next group (the running offsets point at it) into ACT[par]"""
+    a.vmem(f"buffer_load_dwordx4 {vr(ACT[par][0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F0)} offen", f"act0_{par}")
+    a.vmem(f"buffer_load_dwordx4 {vr(ACT[par][1], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F1)} offen", f"act1_{par}")
+
+
+def d8_loads(a, par, tt):
+    s = S_D0 if tt == 0 else S_D1
+    a.vmem(f"buffer_load_dwordx4 {vr(D8[par][tt], 4)}, {vr(V_H32)}, {sr(S_ARSRC, 4)}, {sr(s)} offen", f"d8_{tt}_{par}x")
+    a.vmem(f"buffer_load_dwordx4 {vr(D8[par][tt] + 4, 4)}, {vr(V_H32)}, {sr(S_ARSRC, 4)}, {sr(s)} offen offset:16", f"d8_{tt}_{par}")
+
+
+def advance_offsets(a, g):
+    """after the loads for group g + 1 were issued: step the running offsets to group g + 2 (g = 6: to group 0 of the next super-block)"""
+    if g == 6:
+        for s in (S_F0, S_F1):
+            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, {sr(S_INC6)}")
+        a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_INC6)}, {7 * 1024 - 7 * 64}")     # the d8 offsets step 64 per group: the same jump minus their 7 steps
+        for s in (S_D0, S_D1):
+            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, {sr(S_T0)}")
+    else:
+        for s in (S_F0, S_F1):
+            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
+        for s in (S_D0, S_D1):
+            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 64")
+
+
+def dma_instr(a, j, dst_stage):
+    """LDS-DMA instruction j of a stage: chunk c = 64 j + lane of the row-major [64 rows][BS] image; source = row c / CPR, chunk c % CPR"""
+    t0, t1 = T_DMA, T_DMA + 1
+    a.i(f"v_add_u32 {vr(t0)}, {64 * j}, {vr(V_LANE)}")
+    a.i(f"v_mul_u32_u24 {vr(t1)}, {F.DIV}, {vr(t0)}")
+    a.i(f"v_lshrrev_b32 {vr(t1)}, 16, {vr(t1)}")                        # row = c / CPR
+    a.i(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                          # c * 16
+    a.i(f"v_mad_u32_u24 {vr(t0)}, {vr(t1)}, {sr(S_RBD)}, {vr(t0)}")      # row * (row_bytes - BS) + c * 16 = row * row_bytes + (c % CPR) * 16
+    a.i(f"s_add_u32 m0, {sr(dst_stage)}, {1024 * j}")
+    a.i("s_nop 0")                                                       # SALU write of M0 -> LDS-DMA: one wait state
+    a.vmem(f"buffer_load_dwordx4 {vr(t0)}, {sr(S_WRSRC, 4)}, {sr(S_WKN)} offen lds", "dma")
+
+
+def hdr_read(a, rt):
+    a.lds(f"ds_read_b128 {vr(T_HW + 4 * rt, 4)}, {vr(V_LDSHN)} offset:{rt * 32 * F.BS}", f"hdr{rt}")
+
+
+def hdr_decode(a, rt):
+    """{d | dmin << 16, scales[0..3], scales[4..7], scales[8..11]} -> sc_lo, sc_hi, m_lo, m_hi, d, dmin (get_scale_min_k4 for all 8 groups)"""
+    w = T_HW + 4 * rt
+    h = HDR[rt]
+    t0, t1 = T_HD, T_HD + 1
+    a.wait_lg(f"hdr{rt}")
+    a.i(f"v_and_b32 {vr(h)}, 0x3f3f3f3f, {vr(w + 1)}")                         # sc 0..3
+    a.i(f"v_and_b32 {vr(h + 2)}, 0x3f3f3f3f, {vr(w + 2)}")                     # m 0..3
+    a.i(f"v_lshrrev_b32 {vr(t0)}, 2, {vr(w + 1)}")
+    a.i(f"v_and_b32 {vr(t0)}, 0x30303030, {vr(t0)}")
+    a.i(f"v_and_or_b32 {vr(h + 1)}, {vr(w + 3)}, {sr(S_MASK0F)}, {vr(t0)}")    # sc 4..7
+    a.i(f"v_lshrrev_b32 {vr(t0)}, 2, {vr(w + 2)}")
+    a.i(f"v_and_b32 {vr(t0)}, 0x30303030, {vr(t0)}")
+    a.i(f"v_lshrrev_b32 {vr(t1)}, 4, {vr(w + 3)}")
+    a.i(f"v_and_or_b32 {vr(h + 3)}, {vr(t1)}, {sr(S_MASK0F)}, {vr(t0)}")       # m 4..7
+    a.i(f"v_cvt_f32_f16_sdwa {vr(h + 5)}, {vr(w)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")   # dmin
+    a.i(f"v_cvt_f32_f16_e32 {vr(h + 4)}, {vr(w)}")                              # d
+
+
+def bmin_prep(a, rt, scaled=False):
+    """-dmin * m_g = hi + lo exactly (two fp16 values, hi by round-toward-zero) for the four groups 4 h .. 4 h + 3 of this lane's row,
+    in the K order hi(g0) hi(g1) lo(g0) lo(g1) hi(g2) hi(g3) lo(g2) lo(g3).  Rows with |dmin| > 1024 (the products leave the fp16
+    range) contribute zero here and go through the 2^-8-scaled cold pass (`scaled`), in which the other rows contribute zero."""
+    h = HDR[rt]
+    d = BMIN[rt]
+    t = T_HW          # 10 temporaries: the header-word registers are free outside groups 6 / 7
+    a.i(f"v_cndmask_b32_e64 {vr(t + 8)}, {vr(h + 2)}, {vr(h + 3)}, {sr(S_HI, 2)}")   # m bytes of groups 4 h .. 4 h + 3
+    a.i(f"v_cmp_nle_f32_e64 vcc, |{vr(h + 5)}|, {sr(S_1024)}")                      # |dmin| > 1024 (or NaN)
+    if not scaled:
+        a.i(f"v_cndmask_b32_e64 {vr(t + 9)}, {vr(h + 5)}, 0, vcc")
+    else:
+        a.i(f"v_mul_f32_e32 {vr(t + 9)}, 0x3b800000, {vr(h + 5)}")                  # dmin * 2^-8
+        a.i(f"v_cndmask_b32_e64 {vr(t + 9)}, 0, {vr(t + 9)}, vcc")
+    for j in range(4):
+        a.i(f"v_cvt_f32_ubyte{j} {vr(t + j)}, {vr(t + 8)}")
+    for j in range(4):
+        a.i(f"v_mul_f32_e64 {vr(t + j)}, {vr(t + 9)}, -{vr(t + j)}")                # p_j = -(dm * m_j), exact
+    for j in (0, 2):
+        a.i(f"v_cvt_pkrtz_f16_f32 {vr(d + j)}, {vr(t + j)}, {vr(t + j + 1)}")        # hi pair
+        a.i(f"v_cvt_f32_f16_e32 {vr(t + 4)}, {vr(d + j)}")
+        a.i(f"v_cvt_f32_f16_sdwa {vr(t + 5)}, {vr(d + j)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+        a.i(f"v_sub_f32_e32 {vr(t + 4)}, {vr(t + j)}, {vr(t + 4)}")
+        a.i(f"v_sub_f32_e32 {vr(t + 5)}, {vr(t + j + 1)}, {vr(t + 5)}")
+        a.i(f"v_cvt_pkrtz_f16_f32 {vr(d + j + 1)}, {vr(t + 4)}, {vr(t + 5)}")        # lo pair
+
+
+def s8_loads(a):
+    a.vmem(f"buffer_load_dwordx4 {vr(S8[0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_S8)} offen", "s8_0")
+    a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_S8)}, {REC}")
+    a.vmem(f"buffer_load_dwordx4 {vr(S8[1], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_T0)} offen", "s8_1")
+
+
+def min_mfma(a, ti):
+    if X_NOMIN:
+        return
+    rt, tt = ti & 1, ti >> 1
+    acc = ACC + 16 * ti
+    a.wait_vm(f"s8_{tt}")
+    a.i("s_nop 1")
+    a.i(f"v_mfma_f32_32x32x16_f16 {vr(acc, 16)}, {vr(S8[tt], 4)}, {vr(BMIN[rt], 4)}, {vr(acc, 16)}")
+
+
+def gen(label):
+    a = Asm()
+    # ---------------------------------------------------------------- prologue
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")                     # -12582912.0f
+    for s in (S_256, S_256 + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0x43800000")                     # 256.0f
+    a.i(f"s_mov_b32 {sr(S_MASK0F)}, 0x0f0f0f0f")
+    a.i(f"s_mov_b32 {sr(S_1024)}, 0x44800000")                    # 1024.0f
+    a.i(f"v_cmp_lt_u32_e64 {sr(S_HI, 2)}, 31, {vr(V_LANE)}")      # lanes 32-63
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_LDS)}")                  # LDS byte address of the current stage / of the next one
+    a.i(f"s_add_u32 {sr(S_NSTAGE)}, {sr(S_LDS)}, {F.STAGE}")
+    a.i(f"s_mov_b32 {sr(S_WKN)}, {sr(S_WK)}")                     # stage 0 <- the first super-block of the slice
+    for j in range(F.N_DMA):
+        dma_instr(a, j, S_STAGE)
+    # s8 of the first super-block, activations + token scales of group 0 (same issue order as at the end of the loop body)
+    s8_loads(a)
+    act_loads(a, 0)
+    d8_loads(a, 0, 0)
+    d8_loads(a, 0, 1)
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")                 # the running offsets now point at group 1
+    for s in (S_D0, S_D1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 64")
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
+    a.i(f"v_add_u32 {vr(V_LDSWN)}, {0 if X_NODMA else F.STAGE}, {vr(V_LDSW0)}")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")  # header address of stage 0 (for the prologue only)
+    # result set 1 = magic and zero scales for the first "previous tile" FMA block: it adds exactly zero
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(8):
+        a.i(f"v_mov_b32 {vr(D8[1][1] + k)}, 0")
+    for k in range(4):
+        a.i(f"v_mov_b32 {vr(DWNM[1] + k)}, 0")
+    a.wait_vm("dma")
+    hdr_read(a, 0)
+    hdr_read(a, 1)
+    a.lds(f"ds_read_b128 {vr(RAW[0], 4)}, {vr(V_LDSW)} offset:0", "raw0")
+    a.lds(f"ds_read_b128 {vr(RAW[1], 4)}, {vr(V_LDSW)} offset:{32 * F.BS}", "raw1")
+    hdr_decode(a, 0)
+    hdr_decode(a, 1)
+    w_lo(a, 0)
+    w_lo(a, 1)
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    # ---------------------------------------------------------------- loop over the super-blocks of the slice
+    a.i(f"L_sb_{label}%=:")
+    # (the s8 loads are the oldest operations in flight: the first vmcnt wait of the body — for act0, younger — covers them, so
+    #  they need no entry of their own; the loop body's own s8 loads, issued in group 3, are covered the same way by group 4's waits)
+    assert a.vm[:2] == ["s8_0", "s8_1"]
+    a.vm = a.vm[2:]
+    vm0, lg0 = list(a.vm), list(a.lg)
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")                                               # last super-block of the slice?
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")                              # then "next" = this one again (harmless re-read)
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")                                        # (both selects before anything rewrites SCC)
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
+    a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
+    for g in range(8):
+        q = g >> 1
+        for ti in range(4):
+            rt = ti & 1
+            mfma(a, g, ti)
+            # ---- fillers in the MFMA's issue shadow
+            if g % 2 == 0 and ti < 2:
+                dw_prep(a, q, ti)
+            if ti == 0:
+                act_loads(a, (g + 1) & 1)
+            if ti == 1:
+                d8_loads(a, (g + 1) & 1, 0)
+            if ti == 2:
+                d8_loads(a, (g + 1) & 1, 1)
+                advance_offsets(a, g)
+            if g == 6 and ti == 2:
+                a.wait_vm("dma")                 # the next stage has landed: its header and first pair are read below
+            if ti >= 2:
+                if g % 2 == 0:
+                    w_hi(a, rt)
+                    raw_read(a, rt, q + 1)
+                else:
+                    w_lo(a, rt)
+            if g <= 4 and ti < 2 and 2 * g + ti < F.N_DMA and not X_NODMA:
+                dma_instr(a, 2 * g + ti, S_NSTAGE)   # weight DMA of the next stage: nine instructions over groups 0 .. 4
+            if g == 1 and ti < 2:
+                bmin_prep(a, ti)                 # min-term operand of this super-block
+            if g == 6 and ti == 3:
+                hdr_read(a, 0)                   # header of the next super-block (sc / m of this one are dead by now)
+                hdr_read(a, 1)
+            if g == 7 and ti == 1:
+                hdr_decode(a, 0)
+            if g == 7 and ti == 2:
+                hdr_decode(a, 1)
+            # ---- FMAs of the previous tile (first iteration, tile (7, 3): adds zero)
+            pg, pti = (g, ti - 1) if ti else ((g - 1) % 8, 3)
+            fma_block(a, pg, pti)
+            if g == 2:
+                min_mfma(a, pti)                 # tiles 3, 0, 1, 2 in turn: right after their FMA block, a whole group before the next one
+            if g == 3 and ti == 0:
+                # rows with |dmin| > 1024: cold pass
+                a.i(f"v_cmp_nle_f32_e64 {sr(S_BIG, 2)}, |{vr(HDR[0] + 5)}|, {sr(S_1024)}")
+                a.i(f"v_cmp_nle_f32_e64 vcc, |{vr(HDR[1] + 5)}|, {sr(S_1024)}")
+                a.i(f"s_or_b64 {sr(S_BIG, 2)}, {sr(S_BIG, 2)}, vcc")
+                a.i(f"s_cmp_lg_u64 {sr(S_BIG, 2)}, 0")
+                a.i(f"s_cbranch_scc1 L_cold_{label}%=")
+                a.i(f"L_warm_{label}%=:")
+                s8_loads(a)                      # s8 of the next super-block (the S8 registers are free now)
+    # stage swap + loop control
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_NSTAGE)}")
+    a.i(f"s_mov_b32 {sr(S_NSTAGE)}, {sr(S_T0)}")
+    if not X_NODMA:
+        a.i(f"v_mov_b32 {vr(T_DW)}, {vr(V_LDSW)}")
+        a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSWN)}")
+        a.i(f"v_mov_b32 {vr(V_LDSWN)}, {vr(T_DW)}")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0 and a.lg == lg0, (a.vm, vm0, a.lg, lg0)
+    # ---------------------------------------------------------------- epilogue: the FMAs of the last tile, drain
+    fma_block(a, 7, 3)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.i("s_nop 7")
+    a.i("s_nop 7")                               # the min-term MFMAs have long retired; nothing is in flight when the asm ends
+    a.i(f"s_branch L_end_{label}%=")
+    # ---------------------------------------------------------------- cold pass: rows with |dmin| > 1024 at 2^-8 of their scale, x 256 afterwards
+    a.i(f"L_cold_{label}%=:")
+    bmin_prep(a, 0, scaled=True)
+    bmin_prep(a, 1, scaled=True)
+    z = CSET[1]                                  # free here: tile (2, 3)'s FMAs are done, MFMA(3, 1) comes after
+    for ti in range(4):
+        rt, tt = ti & 1, ti >> 1
+        acc = ACC + 16 * ti
+        a.i(f"v_mfma_f32_32x32x16_f16 {vr(z, 16)}, {vr(S8[tt], 4)}, {vr(BMIN[rt], 4)}, 0")
+        a.i("s_nop 7")
+        a.i("s_nop 7")
+        for j in range(0, 16, 2):
+            a.i(f"v_pk_fma_f32 {vr(acc + j, 2)}, {vr(z + j, 2)}, {sr(S_256, 2)}, {vr(acc + j, 2)}")
+        a.i("s_nop 3")
+    a.i(f"s_branch L_warm_{label}%=")
+    a.i(f"L_end_{label}%=:")
+    return a
+
+
+def emit(a, fn_name):
+    asm = "\n".join(f'      "{l}\\n"' for l in a.lines)
+    outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_H32, V_LDSW0, V_HOFF, V_LANE}
+    clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
+    s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1}
+    clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
+    return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
+static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned h32, unsigned ldsw0,
+                                               unsigned hoff, unsigned lane, __amdgpu_buffer_rsrc_t wrsrc, __amdgpu_buffer_rsrc_t arsrc,
+                                               unsigned lds, unsigned nsb, unsigned sbstride, unsigned wk, unsigned rbd, unsigned f0,
+                                               unsigned f1, unsigned d0, unsigned d1, unsigned s8) {{
+  asm volatile(
+{asm}
+      : "+{{v[0:31]}}"(acc0), "+{{v[32:63]}}"(acc1), "+{{s{S_NSB}}}"(nsb), "+{{s{S_WK}}}"(wk), "+{{s{S_F0}}}"(f0), "+{{s{S_F1}}}"(f1),
+        "+{{s{S_D0}}}"(d0), "+{{s{S_D1}}}"(d1), "+{{s{S_S8}}}"(s8)
+      : "{{v[{MAGICV}:{MAGICV + 15}]}}"(magic), "{{v{V_LANE16}}}"(lane16), "{{v{V_H32}}}"(h32), "{{v{V_LDSW0}}}"(ldsw0), "{{v{V_HOFF}}}"(hoff),
+        "{{v{V_LANE}}}"(lane), "{{s[{S_WRSRC}:{S_WRSRC + 3}]}}"(wrsrc), "{{s[{S_ARSRC}:{S_ARSRC + 3}]}}"(arsrc), "{{s{S_LDS}}}"(lds),
+        "{{s{S_SBSTRIDE}}}"(sbstride), "{{s{S_RBD}}}"(rbd)
+      : "memory", "scc", "vcc", "m0", {clob_s}, {clob_v});
+}}
+'''
+
+
+if __name__ == "__main__":
+    a = gen("q4k")
+    if "--list" in sys.argv:
+        print("\n".join(a.lines))
+    with open(os.environ.get("X64_OUT", OUT), "w") as f:
+        f.write(emit(a, "x64_loop_q4k"))
+    print(len(a.lines), "instructions ->", OUT, file=sys.stderr)

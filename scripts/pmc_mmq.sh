@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): scripts/pmc_mmq.sh TAG [type] [batch]   (env N, K, GGQ_SK_TB pass through)
+# usage (on the GPU box): [WHAT=x64] scripts/pmc_mmq.sh TAG [type] [batch]   (env N, K pass through; WHAT = the run_kernel.py mode, default mmq)
 # three SQ counter passes (8 counters each, never combined with other trace domains) over scripts/run_kernel.py
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; T=${2:-12}; B=${3:-128}
@@ -9,7 +9,7 @@ P2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_L
 P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_WAVE32_LDS"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/scripts/run_kernel.py mmq $T $B 6 > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/scripts/run_kernel.py ${WHAT:-mmq} $T $B 6 > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pass $i failed"
   i=$((i+1))
 done
 python3 - <<PY

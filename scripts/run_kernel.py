@@ -1,5 +1,5 @@
 """Run one hot-path kernel a few times (for rocprofv3 --pmc / --kernel-trace runs).
-usage: python scripts/run_kernel.py {mmq|mmq_ref_layout|t16|mmvq|dequant|quant} [type] [batch] [iters]"""
+usage: python scripts/run_kernel.py {mmq|mmq_ref_layout|t16|x64|mmvq|dequant|quant} [type] [batch] [iters]"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ggml-libtorch_amd"))
@@ -24,6 +24,8 @@ elif what == "mmq_ref_layout":
     L.ggq_quantize_q8_1_mmq(vp(x), 1, vp(scr), batch, K, t, st())
 elif what == "t16":   # the 16-token-tile kernel on its own scratch layout
     assert L.ggq_quantize_q8_1_t16(vp(x), 1, vp(scr), batch, K, t, st()) == 0
+elif what == "x64":   # the 64 x 64 wave-tile kernel on its own scratch layout
+    assert L.ggq_quantize_q8_1_x64(vp(x), 1, vp(scr), batch, K, t, st()) == 0
 for _ in range(iters):
     if what == "mmq":
         L.ggq_mul_mat_q_pretiled(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, st())
@@ -31,6 +33,8 @@ for _ in range(iters):
         L.ggq_mul_mat_q_prequant(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, st())
     elif what == "t16":
         assert L.ggq_mul_mat_q_t16(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, 0, None, st()) == 0
+    elif what == "x64":
+        assert L.ggq_mul_mat_q_x64(vp(w), vp(scr), vp(y), t, 1, batch, K, N, N, 0, None, st()) == 0
     elif what == "mmvq":
         L.ggq_mul_mat_vec_q(vp(w), vp(x), vp(y), t, 1, K, N, vp(scr), st())
     elif what == "dequant":

@@ -27,7 +27,7 @@ def test_hip_library_exports_every_symbol():
     L = ggqlib.hip()  # raises if the .so is missing or a symbol is not exported
     for name in ggqlib.HIP_SYMBOLS:
         assert getattr(L, name) is not None
-    assert L.ggq_abi_version() == 7
+    assert L.ggq_abi_version() == 8
 
 
 def test_cpu_library_exports_every_symbol():
@@ -101,8 +101,12 @@ def test_scratch_and_tiled_traits():
     kernel accepts (every supported format, whole blocks, rows within its 32-bit byte offsets)"""
     L = ggqlib.hip()
     per_token = (4096 - 4096 % 512 + 512) // 32 * 36
-    for batch, tiles in ((1, 32), (32, 32), (33, 64), (128, 128), (129, 160)):
-        assert L.ggq_mmq_scratch_bytes(batch, 4096) == tiles * per_token
+    # ... or, where that is more, the x64 layout's 10240-byte records per (256 elements, 32 tokens) with token tiles in pairs (64 tokens)
+    for batch, tiles, tiles64 in ((1, 32, 64), (32, 32, 64), (33, 64, 64), (128, 128, 128), (129, 160, 192)):
+        assert L.ggq_mmq_scratch_bytes(batch, 4096) == max(tiles * per_token, tiles64 // 32 * 16 * 10240)
+    assert L.ggq_mmq_scratch_bytes(128, 4096) == 663552                        # the reference's figure where it suffices
+    assert L.ggq_mmq_scratch_bytes(128, 8192) == 4 * 32 * 10240 > 128 * 8704 // 32 * 36
+    assert L.ggq_mmq_scratch_bytes(128, 4096 + 32) == 128 * 4608 // 32 * 36    # k not a multiple of 256: no x64 layout
     for t in WEIGHT_TYPES:
         qk = BLOCK[t][0]
         assert L.ggq_mmq_tiled_supported(int(t), 4096) == 1

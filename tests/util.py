@@ -240,3 +240,72 @@ def gpu_mmq_t16(w_np, x, t, n_rows, ldy=None, epilogue=0, aux=None, w_dev=None):
                                      None if aux is None else vp(aux), stream_ptr()), "ggq_mul_mat_q_t16")
     torch.cuda.synchronize()
     return y
+
+
+# ---------------------------------------------------------------- 64 x 64 wave-tile path (mmq_x64.hip)
+X64_REC = 10240
+
+
+def retile_q8_1_x64(q_mmq, batch, k, t):
+    """block_q8_1_mmq bytes (index (k/128)*batch + token) -> the x64 layout of ggq_quantize_q8_1_x64, built in numpy from the layout's
+    definition (include/ggq.h): per (k/256, token/32) a 10240-byte record { frag[8 groups][2 K-halves][32 tokens][16]; d8[8 groups][h][qd][e]
+    (fp16 for the need_sum formats, else fp32; token 8 qd + 4 h + e); fp16 s8[2 kh][32 tokens][8] at byte 9216 (need_sum formats) };
+    the token tiles of one K step are contiguous and padded to an even count.  Returns (records, mask of the bytes the layout defines)."""
+    from ggq.formats import GGMLType as G
+    need_sum = G(int(t)) in (G.Q4_0, G.Q4_1, G.Q5_1, G.Q4_K, G.Q5_K)
+    assert k % 256 == 0
+    n_kb, n_sb, n_tt = k // 128, k // 256, (batch + 63) // 64 * 2
+    blocks = np.asarray(q_mmq, np.uint8)[:n_kb * batch * 144].reshape(n_kb, batch, 144)
+    out = np.zeros((n_sb, n_tt, X64_REC), np.uint8)
+    mask = np.zeros((n_sb, n_tt, X64_REC), bool)
+    for tok in range(batch):
+        tt, tl = divmod(tok, 32)
+        qs = blocks[:, tok, 16:].reshape(n_sb, 8, 2, 16)     # [super-block][group][K-half][16]
+        ds = blocks[:, tok, :16].reshape(n_sb, 8, 4)         # [super-block][group][4 bytes]: half2(d, sum) or float d
+        h, qd, e = (tl >> 2) & 1, tl >> 3, tl & 3
+        idx = h * 16 + qd * 4 + e
+        for g8 in range(8):
+            for kh in range(2):
+                o = g8 * 1024 + kh * 512 + tl * 16
+                out[:, tt, o:o + 16] = qs[:, g8, kh]
+                mask[:, tt, o:o + 16] = True
+            if need_sum:
+                o = 8192 + g8 * 64 + idx * 2
+                out[:, tt, o:o + 2] = ds[:, g8, 0:2]
+                mask[:, tt, o:o + 2] = True
+                j = g8 & 3
+                p0 = (j >> 1) * 4 + (j & 1)
+                for p in (p0, p0 + 2):
+                    o = 9216 + ((g8 >> 2) * 32 + tl) * 16 + 2 * p
+                    out[:, tt, o:o + 2] = ds[:, g8, 2:4]
+                    mask[:, tt, o:o + 2] = True
+            else:
+                o = 8192 + g8 * 128 + idx * 4
+                out[:, tt, o:o + 4] = ds[:, g8]
+                mask[:, tt, o:o + 4] = True
+    return out, mask
+
+
+def gpu_quantize_q8_1_x64(x, t):
+    L = ggqlib.hip()
+    batch, k = x.shape
+    q = torch.zeros(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    ggqlib.check(L.ggq_quantize_q8_1_x64(vp(x), ggqlib.dtype_code(x.dtype), vp(q), batch, k, int(t), stream_ptr()), "quantize_x64")
+    torch.cuda.synchronize()
+    return q.cpu().numpy()
+
+
+def gpu_mmq_x64(w_np, x, t, n_rows, ldy=None, epilogue=0, aux=None, w_dev=None):
+    """quantise into the x64 scratch, then the 64 x 64 wave-tile kernel alone"""
+    L = ggqlib.hip()
+    batch, k = x.shape
+    ldy = n_rows if ldy is None else ldy
+    w = dev_bytes(w_np) if w_dev is None else w_dev
+    y = torch.zeros((batch, ldy), dtype=x.dtype, device="cuda")
+    q = torch.empty(int(L.ggq_mmq_scratch_bytes(batch, k)), dtype=torch.uint8, device="cuda")
+    dt = ggqlib.dtype_code(x.dtype)
+    ggqlib.check(L.ggq_quantize_q8_1_x64(vp(x), dt, vp(q), batch, k, int(t), stream_ptr()), "quantize_x64")
+    ggqlib.check(L.ggq_mul_mat_q_x64(vp(w), vp(q), vp(y), int(t), dt, batch, k, n_rows, ldy, epilogue,
+                                     None if aux is None else vp(aux), stream_ptr()), "ggq_mul_mat_q_x64")
+    torch.cuda.synchronize()
+    return y
