@@ -9,14 +9,16 @@
 // Structure:
 //   workgroup = 4 waves = 4 K-slices of one unit (64 weight rows x 64 tokens); no workgroup barrier in the K loop;
 //   wave tile = 2 x 2 MFMA tiles (v_mfma_i32_32x32x32_i8), lane = weight row, accumulator register = token: the row scale d·sc is a lane
-//     scalar decoded from the row's own header, the token scales come from the scratch as packed fp16 and are read in place by
-//     v_fma_mix_f32 — no scale ever crosses lanes;
+//     scalar decoded from the row's own header, the token scales come from the scratch as fp32 in accumulator-register order —
+//     no scale ever crosses lanes, and both FMA stages are v_pk_fma_f32;
 //   two MFMA result sets: the 8 + 16 FMAs of tile n-1 are issued under the MFMA of tile n, unpack / decode / address work sits in
 //     the MFMA's issue shadow (scripts/ubench_tile.hip: 50-52 ns per tile per SIMD against 100+ in mmq_stream_kernel);
 //   weights: raw super-block bytes, each byte once, row-major by LDS-DMA into a wave-private two-stage ring; the ring's rows are
 //     144 bytes apart = an odd number of 16-byte units: every ds_read_b128 of the loop is conflict-free;
 //   activations: the x64 scratch layout (quantize.hip LAYOUT 5): per (super-block, 32-token tile) 8 fragments of 1 KB in lane
-//     order, the 32 token scales of every group as fp16 in accumulator-register order, the s8 operand of the min-term MFMA;
+//     order (straight into registers, one 32-group ahead), the 32 token scales of every group as fp32 in accumulator-register
+//     order (by LDS-DMA into a 2 KB table beside the ring, read back as broadcast ds_read_b128: as global loads they made the CU's
+//     one texture addresser the limit), the s8 operand of the min-term MFMA;
 //   min term Σ_g (-dmin·m_g)[row]·s8_g[token]: ONE v_mfma_f32_32x32x16_f16 per super-block and tile (exact hi + lo fp16 split, as in
 //     mmq_stream_kernel), rows with |dmin| > 1024 through a 2^-8-scaled cold pass;
 //   K-slice partial sums meet once in LDS and are added in slice order; the write-back reads them back transposed, so that a
@@ -46,7 +48,8 @@ __device__ __forceinline__ float x64_apply_epilogue(float v, int epi, const void
 
 constexpr int X64_REC = 10240;          // bytes of one (super-block, 32-token tile) record of the x64 scratch layout
 constexpr int X64_STAGE = 64 * 144;     // Q4_K: one ring stage = 64 rows x one super-block
-constexpr int X64_LDS = 4 * 2 * X64_STAGE;   // four wave-private rings; the K-slice reduction (64 KB) aliases them
+constexpr int X64_WAVE_LDS = 2 * X64_STAGE + 2048;   // a wave's weight ring + the fp32 token scales of its two token tiles for one K step
+constexpr int X64_LDS = 4 * X64_WAVE_LDS;            // 80 KB: two workgroups fill a CU's 160 KB exactly; the K-slice reduction (64 KB) aliases it
 
 template <int T, int DT>
 __global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
@@ -81,10 +84,13 @@ __global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restri
     const uint32_t n_tt32 = 2u * (uint32_t)n_tok_tiles;                  // 32-token records per super-block
     const uint32_t sbstride = n_tt32 * X64_REC;
     const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
-    const uint32_t ring = (uint32_t)(uintptr_t)lds + (uint32_t)ks * (2 * X64_STAGE);
+    const uint32_t ring = (uint32_t)(uintptr_t)lds + (uint32_t)ks * X64_WAVE_LDS;
     const uint32_t hoff = 16u + 16u * (uint32_t)h;
-    x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, (uint32_t)h * 32u, ring + (uint32_t)r * 144u + hoff, hoff, (uint32_t)lane,
-                 wrsrc, arsrc, ring, (uint32_t)(sb_end - sb_begin), sbstride, (uint32_t)sb_begin * 144u, row_bytes - 144u, f0,
+    // LDS-DMA source offset of this lane inside the seven rows one instruction copies: row lane / 9, 16-byte chunk lane % 9
+    // (lane 63 = chunk 0 of the next instruction's first row: both write the same bytes)
+    const uint32_t dmaoff = (uint32_t)(lane / 9) * row_bytes + (uint32_t)(lane % 9) * 16u;
+    x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, ring + 2 * X64_STAGE + (uint32_t)h * 64u, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff,
+                 wrsrc, arsrc, ring, (uint32_t)(sb_end - sb_begin), sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0,
                  f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
   }
 

@@ -41,8 +41,8 @@ __device__ __forceinline__ void load4(const void* x, int64_t base, int64_t ix, i
 // 2 f + (c >> 1), h = c & 1: the slot is those two 8-element runs, low-nibble run first.
 // LAYOUT 5: the x64 layout (mmq_x64.hip): per (ix/256, token/32) a 10240-byte record
 //           { int8 frag[8 groups][2 K-halves][32 tokens][16]                        8192 bytes, one MFMA operand fragment = 1 KB in lane order
-//             d8[8 groups][2 halves h][4 quads qd][4 e]                              token 8 qd + 4 h + e: accumulator-register order of lane half h;
-//                                                                                    fp16 (64 bytes per group) for the need_sum formats, else fp32 (128)
+//             float d8[8 groups][2 halves h][4 quads qd][4 e]                        token 8 qd + 4 h + e: accumulator-register order of lane half h;
+//                                                                                    the fp16-rounded d as fp32 for the need_sum formats, else d
 //             fp16 s8[2 kh][32 tokens][8] = s8(4kh) s8(4kh+1) s8(4kh) s8(4kh+1) s8(4kh+2) s8(4kh+3) s8(4kh+2) s8(4kh+3)   at byte 9216: the
 //                                                                                    operand of the min-term MFMA (need_sum formats) }
 //           records of a 256-element K step are contiguous over the token tiles, whose count is rounded up to even (64-token units).
@@ -120,10 +120,9 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const void* __restri
     *(uint32_t*)(rec + g8 * 1024 + (e >> 4) * 512 + tl * 16 + (e & 15)) = packed;
     if (e == 0) {
       const int idx = ((tl >> 2) & 1) * 16 + (tl >> 3) * 4 + (tl & 3);   // [h][qd][e]
-      if (NEED_SUM) {
-        const uint16_t hd = __builtin_bit_cast(uint16_t, (_Float16)d);
+      if (NEED_SUM) {   // the reference stores half2(d, sum) for these formats (mmq.cu:137-143): the kernel must see the fp16-rounded values
         const uint16_t hs = __builtin_bit_cast(uint16_t, (_Float16)sum);
-        *(uint16_t*)(rec + 8192 + g8 * 64 + idx * 2) = hd;
+        *(float*)(rec + 8192 + g8 * 128 + idx * 4) = (float)(_Float16)d;
         uint16_t* s8 = (uint16_t*)(rec + 9216 + ((g8 >> 2) * 32 + tl) * 16);
         const int j = g8 & 3, p0 = (j >> 1) * 4 + (j & 1);
         s8[p0] = hs;

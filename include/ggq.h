@@ -202,8 +202,8 @@ int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype
  * HK/ggml/kernel_instances/mmq_kernel.cuh:21-32 + mmq.cuh:1917-1986, at the reference benchmark's own batch sizes,
  * benchmarks/benchmark_mmq.py:152).  K loop in hand-scheduled gfx950 assembly (scripts/gen_mmq_x64.py).  The scratch ("x64 layout",
  * ggq_quantize_q8_1_x64) holds the same Q8_1 values as ggq_quantize_q8_1_mmq, regrouped per (k/256, token/32) into 10240-byte records
- * { int8 frag[8 groups][2 K-halves][32 tokens][16];  d8[8 groups][32 tokens] as fp16 (need_sum formats) or fp32, tokens in
- * accumulator-register order;  fp16 s8 operand of the min-term MFMA [2][32 tokens][8] }, token tiles padded to a multiple of 64
+ * { int8 frag[8 groups][2 K-halves][32 tokens][16];  float d8[8 groups][32 tokens] (the fp16-rounded d for the need_sum formats), tokens
+ * in accumulator-register order;  fp16 s8 operand of the min-term MFMA [2][32 tokens][8] }, token tiles padded to a multiple of 64
  * tokens.  q: >= ggq_mmq_scratch_bytes(batch, k) bytes, 16-byte aligned.  Formats: ggq_mmq_x64_type_supported(); k a multiple of 256,
  * scratch below 4 GiB (ggq_mmq_x64_supported; GGQ_ERR_SHAPE otherwise).  Epilogue arguments as ggq_mul_mat_q_pretiled_epi. */
 int ggq_mmq_x64_type_supported(int type);

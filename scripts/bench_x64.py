@@ -10,7 +10,8 @@ t = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 11008
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 batches = [int(b) for b in (sys.argv[4] if len(sys.argv) > 4 else "64,128,256,512,2048,4096").split(",")]
-L = ggqlib.hip()
+L = ggqlib.hip() if not os.environ.get("GGQ_LIB") else ggqlib._bind(ctypes.CDLL(os.environ["GGQ_LIB"]), ggqlib.HIP_SYMBOLS)
+QUICK = os.environ.get("QUICK")
 vp = lambda x: ctypes.c_void_p(x.data_ptr()); st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 w0 = torch.from_numpy(synth.random_weight(t, N, K, seed=0)).cuda()
 ring = [w0] + [w0.clone() for _ in range(max(1, (352 << 20) // w0.numel()))]
@@ -55,6 +56,9 @@ for b in batches:
     res = {}
     L.ggq_quantize_q8_1_x64(vp(x), 1, vp(scr), b, K, t, st())
     res["x64 kernel warm"] = timeit(lambda i: x64_k(i, [w0]), iters)
+    if QUICK:
+        print(f"type {t} {N}x{K} batch {b}: x64 kernel warm {res['x64 kernel warm']:.1f} us = {ops / res['x64 kernel warm'] / 1e6:.0f} TOP/s", flush=True)
+        continue
     res["x64 kernel cold"] = timeit(x64_k, iters)
     res["x64 op warm"] = timeit(lambda i: x64_op(i, [w0]), iters)
     res["x64 op cold"] = timeit(x64_op, iters)

@@ -40,7 +40,7 @@ def regs_of(text):
 class Ins:
     __slots__ = ("addr", "mn", "ops", "text", "dst", "src", "kind", "target", "wait")
 
-    def __init__(self, addr, text):
+    def __init__(self, addr, text, word=None):
         self.addr, self.text = addr, text
         parts = text.split(None, 1)
         self.mn = parts[0]
@@ -86,7 +86,8 @@ class Ins:
                 self.wait = (int(vm.group(1)) if vm else None, int(lg.group(1)) if lg else None)
         elif mn.startswith(("s_cbranch", "s_branch")):
             self.kind = "cbranch" if mn.startswith("s_cbranch") else "branch"
-            off = int(ops.strip().split()[0], 0)
+            # the branch offset from the encoding when it is there (hand-written asm labels are printed symbolically)
+            off = (word & 0xFFFF) if word is not None else int(ops.strip().split()[0], 0)
             if off >= 32768:
                 off -= 65536
             self.target = addr + 4 + 4 * off
@@ -100,16 +101,18 @@ def parse_kernels(disasm):
     for line in disasm.split("\n"):
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
         if m:
+            if m.group(1).startswith("L_"):   # a label of a hand-written inline-asm loop (mmq_x64_loops.inc), not a function
+                continue
             cur = kernels.setdefault(m.group(1), [])
             continue
         if cur is None or "//" not in line:
             continue
         body, tail = line.split("//", 1)
         body = body.strip()
-        ma = re.match(r"\s*([0-9A-Fa-f]+):", tail)
+        ma = re.match(r"\s*([0-9A-Fa-f]+):\s*([0-9A-Fa-f]{8})?", tail)
         if not body or not ma:
             continue
-        cur.append(Ins(int(ma.group(1), 16), body))
+        cur.append(Ins(int(ma.group(1), 16), body, int(ma.group(2), 16) if ma.group(2) else None))
     return kernels
 
 

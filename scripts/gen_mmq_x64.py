@@ -10,7 +10,7 @@ scripts/ubench_tile.hip measured that stream at 50-52 ns per tile per SIMD (two 
 
 Wave tile: 64 weight rows x 64 tokens (2 x 2 MFMA tiles), lane = weight row, accumulator register = token:
     first stage   t   = fma(12582912 + C, dw, -12582912 dw)   = RN(C * dw) exactly (dw = d * sc has <= 19 significant bits)
-    second stage  acc = fma(t, d8[token], acc)                  d8 fp16 in place (v_fma_mix_f32) for the need_sum formats
+    second stage  acc = fma(t, d8[token], acc)                  d8 as fp32 from the scratch, two tokens per v_pk_fma_f32
 Weights: raw super-block bytes, row-major, by LDS-DMA into a wave-private two-stage ring (one stage = one 256-element K step of 64 rows);
 activations + their scales straight from the x64 scratch layout (quantize.hip LAYOUT 5) into registers, one 32-group ahead.
 
@@ -29,23 +29,24 @@ MAGICV = 96        # v[96:111]  0x4B400000 (input)
 RAW = (112, 116)   # raw quant bytes of the current pair, per row tile
 WOP = (120, 124)   # int8 MFMA operand of the current group, per row tile
 ACT = ((128, 132), (136, 140))          # [group parity][tt]
-D8 = ((144, 152), (160, 168))           # [group parity][tt], 8 registers each = 16 fp16 token scales
-DWNM = (176, 180)  # per row tile: dw_even, dw_odd, nm_even, nm_odd
-HDR = (184, 190)   # per row tile: sc_lo, sc_hi, m_lo, m_hi, d, dmin
-BMIN = (196, 200)  # per row tile: min-term operand (hi / lo split of -dmin * m), 4 registers
-S8 = (204, 208)    # per token tile: s8 operand, 4 registers
-V_LANE16, V_H32, V_LDSW0, V_HOFF, V_LANE = 212, 213, 214, 215, 216          # inputs
-V_LDSW, V_LDSWN, V_LDSHN = 217, 218, 219
-T_DW, T_WHI, T_DMA, T_HW, T_HD = 220, 222, 226, 228, 236                     # temporaries by task (T_HW: header words, 8; also bmin temps)
-N_VGPR = 238
+D8 = (144, 160)                         # [tt], 16 registers each: the fp32 token scales of the current group, accumulator-register order
+DWNM = (176, 184)  # per row tile: (dw, dw) (nm, nm) of the even group, (dw, dw) (nm, nm) of the odd group — duplicated pairs: see fma_block
+HDR = (192, 200)   # per row tile: sc_lo, sc_hi, m_lo, m_hi, d, d, dmin, -
+BMIN = (208, 212)  # per row tile: min-term operand (hi / lo split of -dmin * m), 4 registers
+S8 = (216, 220)    # per token tile: s8 operand, 4 registers
+V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF = 224, 225, 226, 227, 228      # inputs (V_LDSD: LDS address of this lane half's token scales)
+V_LDSW, V_LDSWN, V_LDSHN = 229, 230, 231
+T_DW, T_WHI, T_HW, T_HD = 232, 236, 240, 248                                 # temporaries by task (T_HW: header words, 8; also bmin temps)
+N_VGPR = 250
 
 # SGPRs (physical; the C++ side binds its values to them)
 S_WRSRC, S_ARSRC = 36, 40          # s[36:39] weight tile descriptor, s[40:43] activation scratch descriptor
-S_LDS, S_NSB, S_SBSTRIDE, S_WK, S_RBD = 44, 45, 46, 47, 48     # S_RBD = row_bytes - bytes of a row in one stage
-S_F0, S_F1, S_D0, S_D1, S_S8 = 49, 50, 51, 52, 53               # running byte offsets into the scratch
+S_LDS, S_NSB, S_SBSTRIDE, S_WK, S_RB7 = 44, 45, 46, 47, 48     # S_RB7 = 7 * row_bytes: the rows one DMA instruction covers
+S_F0, S_F1, S_D0, S_D1, S_S8 = 49, 50, 51, 52, 53               # byte offsets into the scratch: running fragment offsets, d8 tables and s8 operand of the current super-block
 S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN = 54, 55, 56, 57, 58, 59
 S_NEGM, S_1024, S_MASK0F, S_HI = 60, 62, 63, 66                  # s[60:61] = -12582912.0f x 2; s[66:67] = lanes 32-63
-S_BIG, S_256 = 68, 70                                            # s[68:69] cold-path mask, s[70:71] = 256.0f x 2
+S_NEXT = 74                                                      # byte distance to the next super-block's records (0 on the last one of the slice)
+S_BIG, S_256, S_EXEC = 68, 70, 72                                # s[68:69] cold-path mask, s[70:71] = 256.0f x 2, s[72:73] saved exec
 REC = 10240        # bytes of one (super-block, 32-token tile) record of the scratch
 ROWS = 64
 # experiment switches (scripts only; the shipped .inc is generated with the defaults)
@@ -54,6 +55,9 @@ X_NOPS = int(os.environ.get("X64_NOPS", "0"))          # s_nop wait states after
 TSET = 240
 X_NOMIN = int(os.environ.get("X64_NOMIN", "0"))        # 1: no min-term MFMA (wrong results; determinism experiments only)
 X_PLAIN2 = int(os.environ.get("X64_PLAIN2", "0"))      # 1: second stage as plain v_fma_f32 on the raw d8 dwords (wrong results; determinism experiments only)
+X_NOD8 = int(os.environ.get("X64_NOD8", "0"))          # 1: no token-scale loads inside the loop (wrong results; timing experiments only)
+X_NOACT = int(os.environ.get("X64_NOACT", "0"))        # 1: no activation-fragment loads inside the loop (wrong results; timing experiments only)
+X_NOFILL = int(os.environ.get("X64_NOFILL", "0"))      # timing experiments only (wrong results): 1 no dw_prep, 2 no unpack + raw reads, 8 no header decode inside the loop
 X_NODMA = int(os.environ.get("X64_NODMA", "0"))        # 1: no LDS-DMA inside the loop, every super-block re-reads stage 0 (wrong results; determinism experiments only)
 
 
@@ -106,7 +110,7 @@ class Q4K:
     name, type_id = "q4k", 12
     BS = 144                 # bytes of a row in one stage (one super-block)
     CPR, DIV = 9, 7282       # 16-byte chunks per row of a stage; c / CPR = (c * DIV) >> 16
-    N_DMA = 9                # LDS-DMA instructions per stage (64 rows x CPR chunks / 64 lanes)
+    N_DMA = 10               # LDS-DMA instructions per stage: 7 rows (63 chunks) each, the last one row 63 alone
     QS_OFF = 16              # first quant byte inside the super-block
     STAGE = ROWS * 144
 
@@ -127,33 +131,35 @@ def mfma(a, g, ti):
 
 
 def fma_block(a, g, ti):
-    """the two exact FMAs per triple of tile (g, ti); its MFMA was issued one tile ago"""
+    """the two exact FMAs per triple of tile (g, ti); its MFMA was issued one tile ago.  Both stages packed (v_pk_fma_f32): the second
+    stage read the token scales as packed fp16 through v_fma_mix_f32 at first — half the scale registers — but with two waves per
+    SIMD that instruction returned wrong low-half results in lanes 48-63 from time to time (profiles/r04_x64_nondeterminism.txt);
+    with plain or packed fp32 FMAs the kernel is bit-reproducible."""
     rt, tt = ti & 1, ti >> 1
     c = CSET[(4 * g + ti) & 1]
     p = g & 1
     if ti in (0, 2):
-        a.wait_vm(f"d8_{tt}_{p}")
-    dw, nm = DWNM[rt], DWNM[rt] + 2
+        a.wait_lg(f"d8_{tt}")
+    dw, nm = DWNM[rt] + 4 * p, DWNM[rt] + 4 * p + 2
     tdst = c if X_INPLACE else TSET
     for j in range(0, 16, 2):
-        a.i(f"v_pk_fma_f32 {vr(tdst + j, 2)}, {vr(c + j, 2)}, {vr(dw, 2)}, {vr(nm, 2)} op_sel:[0,{p},{p}] op_sel_hi:[1,{p},{p}]")
+        a.i(f"v_pk_fma_f32 {vr(tdst + j, 2)}, {vr(c + j, 2)}, {vr(dw, 2)}, {vr(nm, 2)}")
     acc = ACC + 16 * ti
-    d8 = D8[p][tt]
-    for i in range(16):
-        if X_PLAIN2:
-            a.i(f"v_fma_f32 {vr(acc + i)}, {vr(tdst + i)}, {vr(d8 + (i >> 1))}, {vr(acc + i)}")
-        else:
-            a.i(f"v_fma_mix_f32 {vr(acc + i)}, {vr(tdst + i)}, {vr(d8 + (i >> 1))}, {vr(acc + i)} op_sel:[0,{i & 1},0] op_sel_hi:[0,1,0]")
+    d8 = D8[tt]
+    for j in range(0, 16, 2):
+        a.i(f"v_pk_fma_f32 {vr(acc + j, 2)}, {vr(tdst + j, 2)}, {vr(d8 + j, 2)}, {vr(acc + j, 2)}")
 
 
 def dw_prep(a, q, rt):
-    """row scales of groups 2q, 2q+1: dw = d * sc, nm = -12582912 * dw"""
+    """row scales of groups 2q, 2q+1: dw = d * sc, nm = -12582912 * dw, each as a DUPLICATED register pair, so that the first FMA stage
+    needs no op_sel broadcast (fma_block)"""
     sc = HDR[rt] + (q >> 1)
     b0 = 2 * (q & 1)
-    a.i(f"v_cvt_f32_ubyte{b0} {vr(T_DW)}, {vr(sc)}")
-    a.i(f"v_cvt_f32_ubyte{b0 + 1} {vr(T_DW + 1)}, {vr(sc)}")
-    a.i(f"v_pk_mul_f32 {vr(DWNM[rt], 2)}, {vr(T_DW, 2)}, {vr(HDR[rt] + 4, 2)} op_sel_hi:[1,0]")
-    a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 2, 2)}, {vr(DWNM[rt], 2)}, {sr(S_NEGM, 2)}")
+    for k in range(4):
+        a.i(f"v_cvt_f32_ubyte{b0 + (k >> 1)} {vr(T_DW + k)}, {vr(sc)}")
+    for par in range(2):
+        a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 4 * par, 2)}, {vr(T_DW + 2 * par, 2)}, {vr(HDR[rt] + 4, 2)}")
+        a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 4 * par + 2, 2)}, {vr(DWNM[rt] + 4 * par, 2)}, {sr(S_NEGM, 2)}")
 
 
 def w_hi(a, rt):
@@ -177,44 +183,65 @@ def raw_read(a, rt, q):
         a.lds(f"ds_read_b128 {vr(RAW[rt], 4)}, {vr(V_LDSWN)} offset:{rt * 32 * F.BS}", f"raw{rt}")
 
 
+X_NOACT_ARMED = [False]
 def act_loads(a, par):
     """activation fragments of the next group (the running offsets point at it) into ACT[par]"""
+    if X_NOACT and X_NOACT_ARMED[0]:
+        return
     a.vmem(f"buffer_load_dwordx4 {vr(ACT[par][0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F0)} offen", f"act0_{par}")
     a.vmem(f"buffer_load_dwordx4 {vr(ACT[par][1], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F1)} offen", f"act1_{par}")
 
 
-def d8_loads(a, par, tt):
+def d8_reads(a, tt, target):
+    """the 16 fp32 token scales of group `target` for this lane half (64 contiguous bytes of the wave's LDS table) into D8[tt]: four
+    broadcast ds_read_b128, issued right after the last FMA block that reads the current ones (two to three tiles of lead).
+    (As global loads these cost 8 vector-memory instructions per group: with them the kernel was bound by the CU's one texture
+    addresser, 46 of its cycles per tile where a tile has 22 — profiles/r04_x64_ablations.txt.)"""
+    if target == 4:
+        a.wait_vm(f"d8dma1_{tt}")        # groups 4-7 of this super-block: requested in its first group
+    if target == 0:
+        a.wait_vm(f"d8dma0_{tt}")        # groups 0-3 of the next super-block: requested in group 3 / 4
+    for k in range(4):
+        a.lds(f"ds_read_b128 {vr(D8[tt] + 4 * k, 4)}, {vr(V_LDSD)} offset:{1024 * tt + 128 * target + 16 * k}", f"d8_{tt}" if k == 3 else f"d8_{tt}x")
+
+
+def d8_dma(a, tt, half, nxt):
+    """LDS-DMA of four groups' token scales (512 bytes, 32 lanes) of token tile tt: half 1 = groups 4-7 of THIS super-block (their
+    table slots held the previous one's until its group-7 reads), half 0 with nxt = groups 0-3 of the NEXT one"""
     s = S_D0 if tt == 0 else S_D1
-    a.vmem(f"buffer_load_dwordx4 {vr(D8[par][tt], 4)}, {vr(V_H32)}, {sr(S_ARSRC, 4)}, {sr(s)} offen", f"d8_{tt}_{par}x")
-    a.vmem(f"buffer_load_dwordx4 {vr(D8[par][tt] + 4, 4)}, {vr(V_H32)}, {sr(S_ARSRC, 4)}, {sr(s)} offen offset:16", f"d8_{tt}_{par}")
+    a.i(f"s_add_u32 {sr(S_T0)}, {sr(s)}, {512 * half}")
+    if nxt:
+        a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_NEXT)}")
+    a.i(f"s_add_u32 m0, {sr(S_LDS)}, {2 * F.STAGE + 1024 * tt + 512 * half}")
+    a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
+    a.i("s_mov_b64 exec, 0xffffffff")
+    a.vmem(f"buffer_load_dwordx4 {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_T0)} offen lds", f"d8dma{half}_{tt}")
+    a.i(f"s_mov_b64 exec, {sr(S_EXEC, 2)}")
 
 
 def advance_offsets(a, g):
-    """after the loads for group g + 1 were issued: step the running offsets to group g + 2 (g = 6: to group 0 of the next super-block)"""
-    if g == 6:
-        for s in (S_F0, S_F1):
-            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, {sr(S_INC6)}")
-        a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_INC6)}, {7 * 1024 - 7 * 64}")     # the d8 offsets step 64 per group: the same jump minus their 7 steps
-        for s in (S_D0, S_D1):
-            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, {sr(S_T0)}")
-    else:
-        for s in (S_F0, S_F1):
-            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
-        for s in (S_D0, S_D1):
-            a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 64")
+    """after the fragment loads for group g + 1 were issued: step their running offsets to group g + 2 (g = 6: to group 0 of the next super-block)"""
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, {sr(S_INC6) if g == 6 else '0x400'}")
 
 
 def dma_instr(a, j, dst_stage):
-    """LDS-DMA instruction j of a stage: chunk c = 64 j + lane of the row-major [64 rows][BS] image; source = row c / CPR, chunk c % CPR"""
-    t0, t1 = T_DMA, T_DMA + 1
-    a.i(f"v_add_u32 {vr(t0)}, {64 * j}, {vr(V_LANE)}")
-    a.i(f"v_mul_u32_u24 {vr(t1)}, {F.DIV}, {vr(t0)}")
-    a.i(f"v_lshrrev_b32 {vr(t1)}, 16, {vr(t1)}")                        # row = c / CPR
-    a.i(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                          # c * 16
-    a.i(f"v_mad_u32_u24 {vr(t0)}, {vr(t1)}, {sr(S_RBD)}, {vr(t0)}")      # row * (row_bytes - BS) + c * 16 = row * row_bytes + (c % CPR) * 16
-    a.i(f"s_add_u32 m0, {sr(dst_stage)}, {1024 * j}")
-    a.i("s_nop 0")                                                       # SALU write of M0 -> LDS-DMA: one wait state
-    a.vmem(f"buffer_load_dwordx4 {vr(t0)}, {sr(S_WRSRC, 4)}, {sr(S_WKN)} offen lds", "dma")
+    """LDS-DMA instruction j of a stage: rows 7 j .. 7 j + 6 of the row-major [64 rows][BS] image (lane = chunk 63 j + lane; lane 63
+    repeats lane 0 of instruction j + 1, so both write the same bytes).  Per-lane source offset = one constant register (row lane / CPR of
+    the seven, chunk lane % CPR), the rest is scalar: soffset = K position + 7 j rows.  The last instruction holds row 63 only."""
+    if j == 0:
+        a.i(f"s_mov_b32 {sr(S_T1)}, {sr(S_WKN)}")
+    else:
+        a.i(f"s_add_u32 {sr(S_T1)}, {sr(S_T1)}, {sr(S_RB7)}")
+    a.i(f"s_add_u32 m0, {sr(dst_stage)}, {16 * 7 * F.CPR * j}")
+    if j == F.N_DMA - 1:
+        a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
+        a.i(f"s_mov_b64 exec, {hex((1 << (F.CPR * (ROWS - 7 * j))) - 1)}")
+    else:
+        a.i("s_nop 0")                                                   # SALU write of M0 -> LDS-DMA: one wait state
+    a.vmem(f"buffer_load_dwordx4 {vr(V_DMAOFF)}, {sr(S_WRSRC, 4)}, {sr(S_T1)} offen lds", "dma")
+    if j == F.N_DMA - 1:
+        a.i(f"s_mov_b64 exec, {sr(S_EXEC, 2)}")
 
 
 def hdr_read(a, rt):
@@ -236,8 +263,9 @@ def hdr_decode(a, rt):
     a.i(f"v_and_b32 {vr(t0)}, 0x30303030, {vr(t0)}")
     a.i(f"v_lshrrev_b32 {vr(t1)}, 4, {vr(w + 3)}")
     a.i(f"v_and_or_b32 {vr(h + 3)}, {vr(t1)}, {sr(S_MASK0F)}, {vr(t0)}")       # m 4..7
-    a.i(f"v_cvt_f32_f16_sdwa {vr(h + 5)}, {vr(w)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")   # dmin
-    a.i(f"v_cvt_f32_f16_e32 {vr(h + 4)}, {vr(w)}")                              # d
+    a.i(f"v_cvt_f32_f16_sdwa {vr(h + 6)}, {vr(w)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")   # dmin
+    a.i(f"v_cvt_f32_f16_e32 {vr(h + 4)}, {vr(w)}")                              # d, twice: a pair for the packed multiplies
+    a.i(f"v_cvt_f32_f16_e32 {vr(h + 5)}, {vr(w)}")
 
 
 def bmin_prep(a, rt, scaled=False):
@@ -248,11 +276,11 @@ def bmin_prep(a, rt, scaled=False):
     d = BMIN[rt]
     t = T_HW          # 10 temporaries: the header-word registers are free outside groups 6 / 7
     a.i(f"v_cndmask_b32_e64 {vr(t + 8)}, {vr(h + 2)}, {vr(h + 3)}, {sr(S_HI, 2)}")   # m bytes of groups 4 h .. 4 h + 3
-    a.i(f"v_cmp_nle_f32_e64 vcc, |{vr(h + 5)}|, {sr(S_1024)}")                      # |dmin| > 1024 (or NaN)
+    a.i(f"v_cmp_nle_f32_e64 vcc, |{vr(h + 6)}|, {sr(S_1024)}")                      # |dmin| > 1024 (or NaN)
     if not scaled:
-        a.i(f"v_cndmask_b32_e64 {vr(t + 9)}, {vr(h + 5)}, 0, vcc")
+        a.i(f"v_cndmask_b32_e64 {vr(t + 9)}, {vr(h + 6)}, 0, vcc")
     else:
-        a.i(f"v_mul_f32_e32 {vr(t + 9)}, 0x3b800000, {vr(h + 5)}")                  # dmin * 2^-8
+        a.i(f"v_mul_f32_e32 {vr(t + 9)}, 0x3b800000, {vr(h + 6)}")                  # dmin * 2^-8
         a.i(f"v_cndmask_b32_e64 {vr(t + 9)}, 0, {vr(t + 9)}, vcc")
     for j in range(4):
         a.i(f"v_cvt_f32_ubyte{j} {vr(t + j)}, {vr(t + 8)}")
@@ -292,7 +320,7 @@ def gen(label):
         a.i(f"s_mov_b32 {sr(s)}, 0x43800000")                     # 256.0f
     a.i(f"s_mov_b32 {sr(S_MASK0F)}, 0x0f0f0f0f")
     a.i(f"s_mov_b32 {sr(S_1024)}, 0x44800000")                    # 1024.0f
-    a.i(f"v_cmp_lt_u32_e64 {sr(S_HI, 2)}, 31, {vr(V_LANE)}")      # lanes 32-63
+    a.i(f"v_cmp_ne_u32_e64 {sr(S_HI, 2)}, 16, {vr(V_HOFF)}")      # lanes 32-63 (hoff = 16 + 16 h)
     a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_LDS)}")                  # LDS byte address of the current stage / of the next one
     a.i(f"s_add_u32 {sr(S_NSTAGE)}, {sr(S_LDS)}, {F.STAGE}")
     a.i(f"s_mov_b32 {sr(S_WKN)}, {sr(S_WK)}")                     # stage 0 <- the first super-block of the slice
@@ -300,24 +328,24 @@ def gen(label):
         dma_instr(a, j, S_STAGE)
     # s8 of the first super-block, activations + token scales of group 0 (same issue order as at the end of the loop body)
     s8_loads(a)
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    d8_dma(a, 0, 0, False)                                        # groups 0-3 of the first super-block (4-7: in the loop's first group, as in every iteration)
+    d8_dma(a, 1, 0, False)
     act_loads(a, 0)
-    d8_loads(a, 0, 0)
-    d8_loads(a, 0, 1)
     for s in (S_F0, S_F1):
-        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")                 # the running offsets now point at group 1
-    for s in (S_D0, S_D1):
-        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 64")
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")                 # the fragment offsets now point at group 1
     a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
     a.i(f"v_add_u32 {vr(V_LDSWN)}, {0 if X_NODMA else F.STAGE}, {vr(V_LDSW0)}")
     a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")  # header address of stage 0 (for the prologue only)
     # result set 1 = magic and zero scales for the first "previous tile" FMA block: it adds exactly zero
     for k in range(16):
         a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[1] + k)}, 0")
     for k in range(8):
-        a.i(f"v_mov_b32 {vr(D8[1][1] + k)}, 0")
-    for k in range(4):
         a.i(f"v_mov_b32 {vr(DWNM[1] + k)}, 0")
     a.wait_vm("dma")
+    a.wait_vm("d8dma0_1")
     hdr_read(a, 0)
     hdr_read(a, 1)
     a.lds(f"ds_read_b128 {vr(RAW[0], 4)}, {vr(V_LDSW)} offset:0", "raw0")
@@ -326,13 +354,15 @@ def gen(label):
     hdr_decode(a, 1)
     w_lo(a, 0)
     w_lo(a, 1)
+    d8_reads(a, 0, 0)                                             # (token tile 1's: after the first slot's FMA block, as in every iteration)
     a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
     # ---------------------------------------------------------------- loop over the super-blocks of the slice
+    X_NOACT_ARMED[0] = True
     a.i(f"L_sb_{label}%=:")
     # (the s8 loads are the oldest operations in flight: the first vmcnt wait of the body — for act0, younger — covers them, so
     #  they need no entry of their own; the loop body's own s8 loads, issued in group 3, are covered the same way by group 4's waits)
-    assert a.vm[:2] == ["s8_0", "s8_1"]
-    a.vm = a.vm[2:]
+    if a.vm[:2] == ["s8_0", "s8_1"]:
+        a.vm = a.vm[2:]
     vm0, lg0 = list(a.vm), list(a.lg)
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")                                               # last super-block of the slice?
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")                              # then "next" = this one again (harmless re-read)
@@ -340,24 +370,21 @@ def gen(label):
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
     a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
     for g in range(8):
         q = g >> 1
         for ti in range(4):
             rt = ti & 1
             mfma(a, g, ti)
             # ---- fillers in the MFMA's issue shadow
-            if g % 2 == 0 and ti < 2:
+            if g % 2 == 0 and ti < 2 and not (X_NOFILL & 1):
                 dw_prep(a, q, ti)
             if ti == 0:
                 act_loads(a, (g + 1) & 1)
-            if ti == 1:
-                d8_loads(a, (g + 1) & 1, 0)
-            if ti == 2:
-                d8_loads(a, (g + 1) & 1, 1)
                 advance_offsets(a, g)
             if g == 6 and ti == 2:
                 a.wait_vm("dma")                 # the next stage has landed: its header and first pair are read below
-            if ti >= 2:
+            if ti >= 2 and not (X_NOFILL & 2):
                 if g % 2 == 0:
                     w_hi(a, rt)
                     raw_read(a, rt, q + 1)
@@ -365,24 +392,35 @@ def gen(label):
                     w_lo(a, rt)
             if g <= 4 and ti < 2 and 2 * g + ti < F.N_DMA and not X_NODMA:
                 dma_instr(a, 2 * g + ti, S_NSTAGE)   # weight DMA of the next stage: nine instructions over groups 0 .. 4
+            if g == 0 and ti >= 2:
+                d8_dma(a, ti - 2, 1, False)      # token scales of groups 4-7 of this super-block
+            if (g, ti) == (3, 2):
+                d8_dma(a, 0, 0, True)            # ... of groups 0-3 of the next one (this one's were consumed by FMA(3, 0) / FMA(3, 2))
+            if (g, ti) == (4, 0):
+                d8_dma(a, 1, 0, True)
             if g == 1 and ti < 2:
                 bmin_prep(a, ti)                 # min-term operand of this super-block
-            if g == 6 and ti == 3:
+            if g == 6 and ti == 3 and not (X_NOFILL & 8):
                 hdr_read(a, 0)                   # header of the next super-block (sc / m of this one are dead by now)
                 hdr_read(a, 1)
-            if g == 7 and ti == 1:
+            if g == 7 and ti == 1 and not (X_NOFILL & 8):
                 hdr_decode(a, 0)
-            if g == 7 and ti == 2:
+            if g == 7 and ti == 2 and not (X_NOFILL & 8):
                 hdr_decode(a, 1)
             # ---- FMAs of the previous tile (first iteration, tile (7, 3): adds zero)
             pg, pti = (g, ti - 1) if ti else ((g - 1) % 8, 3)
             fma_block(a, pg, pti)
-            if g == 2:
-                min_mfma(a, pti)                 # tiles 3, 0, 1, 2 in turn: right after their FMA block, a whole group before the next one
+            if pti == 1:
+                d8_reads(a, 0, (pg + 1) % 8)     # token tile 0's scales of the next group (tiles 0 and 1 have read the current ones)
+            if pti == 3:
+                d8_reads(a, 1, (pg + 1) % 8)
+            if pg == 2:
+                min_mfma(a, pti)                 # right after the tile's group-2 FMA block, for every tile (the same summation order in all four:
+                                                 # a row's result must not depend on which half of the unit it sits in), a group before its next one
             if g == 3 and ti == 0:
                 # rows with |dmin| > 1024: cold pass
-                a.i(f"v_cmp_nle_f32_e64 {sr(S_BIG, 2)}, |{vr(HDR[0] + 5)}|, {sr(S_1024)}")
-                a.i(f"v_cmp_nle_f32_e64 vcc, |{vr(HDR[1] + 5)}|, {sr(S_1024)}")
+                a.i(f"v_cmp_nle_f32_e64 {sr(S_BIG, 2)}, |{vr(HDR[0] + 6)}|, {sr(S_1024)}")
+                a.i(f"v_cmp_nle_f32_e64 vcc, |{vr(HDR[1] + 6)}|, {sr(S_1024)}")
                 a.i(f"s_or_b64 {sr(S_BIG, 2)}, {sr(S_BIG, 2)}, vcc")
                 a.i(f"s_cmp_lg_u64 {sr(S_BIG, 2)}, 0")
                 a.i(f"s_cbranch_scc1 L_cold_{label}%=")
@@ -390,6 +428,8 @@ def gen(label):
                 s8_loads(a)                      # s8 of the next super-block (the S8 registers are free now)
     # stage swap + loop control
     a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
     a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
     a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_NSTAGE)}")
     a.i(f"s_mov_b32 {sr(S_NSTAGE)}, {sr(S_T0)}")
@@ -401,7 +441,10 @@ def gen(label):
     a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
     a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
     a.i(f"s_cbranch_scc1 L_sb_{label}%=")
-    assert a.vm == vm0 and a.lg == lg0, (a.vm, vm0, a.lg, lg0)
+    # the operations in flight at the end of the body must be the YOUNGEST ones of those in flight at its top, in the same order: every
+    # wait count of the body (= operations younger than the awaited one) then holds on the second and later iterations too (what the
+    # top-of-loop queue holds beyond that suffix is known complete by then: its waits are satisfied at once)
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0, (a.vm, vm0, a.lg, lg0)
     # ---------------------------------------------------------------- epilogue: the FMAs of the last tile, drain
     fma_block(a, 7, 3)
     a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -429,23 +472,24 @@ def gen(label):
 
 def emit(a, fn_name):
     asm = "\n".join(f'      "{l}\\n"' for l in a.lines)
-    outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_H32, V_LDSW0, V_HOFF, V_LANE}
+    outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
     clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
-    s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1}
+    s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1,
+             S_EXEC, S_EXEC + 1, S_NEXT}
     clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
     return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
-static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned h32, unsigned ldsw0,
-                                               unsigned hoff, unsigned lane, __amdgpu_buffer_rsrc_t wrsrc, __amdgpu_buffer_rsrc_t arsrc,
-                                               unsigned lds, unsigned nsb, unsigned sbstride, unsigned wk, unsigned rbd, unsigned f0,
+static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,
+                                               unsigned hoff, unsigned dmaoff, __amdgpu_buffer_rsrc_t wrsrc, __amdgpu_buffer_rsrc_t arsrc,
+                                               unsigned lds, unsigned nsb, unsigned sbstride, unsigned wk, unsigned rb7, unsigned f0,
                                                unsigned f1, unsigned d0, unsigned d1, unsigned s8) {{
   asm volatile(
 {asm}
       : "+{{v[0:31]}}"(acc0), "+{{v[32:63]}}"(acc1), "+{{s{S_NSB}}}"(nsb), "+{{s{S_WK}}}"(wk), "+{{s{S_F0}}}"(f0), "+{{s{S_F1}}}"(f1),
         "+{{s{S_D0}}}"(d0), "+{{s{S_D1}}}"(d1), "+{{s{S_S8}}}"(s8)
-      : "{{v[{MAGICV}:{MAGICV + 15}]}}"(magic), "{{v{V_LANE16}}}"(lane16), "{{v{V_H32}}}"(h32), "{{v{V_LDSW0}}}"(ldsw0), "{{v{V_HOFF}}}"(hoff),
-        "{{v{V_LANE}}}"(lane), "{{s[{S_WRSRC}:{S_WRSRC + 3}]}}"(wrsrc), "{{s[{S_ARSRC}:{S_ARSRC + 3}]}}"(arsrc), "{{s{S_LDS}}}"(lds),
-        "{{s{S_SBSTRIDE}}}"(sbstride), "{{s{S_RBD}}}"(rbd)
-      : "memory", "scc", "vcc", "m0", {clob_s}, {clob_v});
+      : "{{v[{MAGICV}:{MAGICV + 15}]}}"(magic), "{{v{V_LANE16}}}"(lane16), "{{v{V_LDSD}}}"(ldsd), "{{v{V_LDSW0}}}"(ldsw0), "{{v{V_HOFF}}}"(hoff),
+        "{{v{V_DMAOFF}}}"(dmaoff), "{{s[{S_WRSRC}:{S_WRSRC + 3}]}}"(wrsrc), "{{s[{S_ARSRC}:{S_ARSRC + 3}]}}"(arsrc), "{{s{S_LDS}}}"(lds),
+        "{{s{S_SBSTRIDE}}}"(sbstride), "{{s{S_RB7}}}"(rb7)
+      : "memory", "scc", "vcc", "m0", "exec", {clob_s}, {clob_v});
 }}
 '''
 

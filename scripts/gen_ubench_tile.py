@@ -5,7 +5,7 @@ the MFMA of tile n).  Variants: extra plain VALU ops per tile, LDS reads per til
 This is the design probe for the round-4 big-tile kernel."""
 import sys
 
-def body(pk, extra, lds, nops, extra_pos="end", srcc0=False, salu=0, split=False):
+def body(pk, extra, lds, nops, extra_pos="end", srcc0=False, salu=0, split=False, mix=False):
     """one loop iteration = 4 tiles (a 2x2 wave tile, one 32-group); registers: acc v[0:63], C0 v[64:79], C1 v[80:95], magic v[96:111],
     A frags v[112:119], B frags v[120:127], d8 v[128:159] (two token tiles x 16), dw/nm v[160:163], scratch v[164:171], lds addr v172"""
     L = []
@@ -34,6 +34,11 @@ def body(pk, extra, lds, nops, extra_pos="end", srcc0=False, salu=0, split=False
                 if i >= 8:
                     j = i - 8
                     L.append(f"v_pk_fma_f32 v[{accb+j}:{accb+j+1}], v[{prev+j}:{prev+j+1}], v[{d8+j}:{d8+j+1}], v[{accb+j}:{accb+j+1}]")
+        elif pk and mix:
+            for i in range(0, 16, 2):
+                L.append(f"v_pk_fma_f32 v[{prev+i}:{prev+i+1}], v[{prev+i}:{prev+i+1}], v[{dw}:{dw+1}], v[{dw}:{dw+1}] op_sel:[0,0,1] op_sel_hi:[1,0,1]")
+            for i in range(16):
+                L.append(f"v_fma_mix_f32 v{accb+i}, v{prev+i}, v{d8+(i>>1)}, v{accb+i} op_sel:[0,{i&1},0] op_sel_hi:[0,1,0]")
         elif pk:
             for i in range(0, 16, 2):
                 L.append(f"v_pk_fma_f32 v[{prev+i}:{prev+i+1}], v[{prev+i}:{prev+i+1}], v[{dw}:{dw+1}], v[{dw}:{dw+1}] op_sel:[0,0,1] op_sel_hi:[1,0,1]")
@@ -81,7 +86,9 @@ VARIANTS = [("pk_e0", 1, 0, 0, 0, {}), ("pl_e0", 0, 0, 0, 0, {}), ("pk_e0_n1", 1
             ("pk_e0_n8", 1, 0, 0, 8, {}), ("pk_e0_n16", 1, 0, 0, 16, {}), ("pl_e0_n4", 0, 0, 0, 4, {}), ("pk_e0_c0", 1, 0, 0, 0, dict(srcc0=True)),
             ("pk_e0_c0n4", 1, 0, 0, 4, dict(srcc0=True)), ("pk_e0_s4", 1, 0, 0, 0, dict(salu=4)), ("pk_e4_am", 1, 4, 0, 0, dict(extra_pos="after_mfma")),
             ("pk_e8_am", 1, 8, 0, 0, dict(extra_pos="after_mfma")), ("pk_e8", 1, 8, 0, 0, {}), ("pk_e8_n4", 1, 8, 0, 4, {}), ("pk_e0_sp", 1, 0, 0, 0, dict(split=True)),
-            ("pk_e0_spn4", 1, 0, 0, 4, dict(split=True)), ("pk_e8_l2n4", 1, 8, 2, 4, {}), ("pk_e8_amn4", 1, 8, 0, 4, dict(extra_pos="after_mfma"))]
+            ("pk_e0_spn4", 1, 0, 0, 4, dict(split=True)), ("pk_e8_l2n4", 1, 8, 2, 4, {}), ("pk_e8_amn4", 1, 8, 0, 4, dict(extra_pos="after_mfma")),
+            ("mix_e0", 1, 0, 0, 0, dict(mix=True)), ("mix_e8_am", 1, 8, 0, 0, dict(mix=True, extra_pos="after_mfma")), ("pl_e8_am", 0, 8, 0, 0, dict(extra_pos="after_mfma")),
+            ("pk_e12_am", 1, 12, 0, 0, dict(extra_pos="after_mfma")), ("pk_e16_am", 1, 16, 0, 0, dict(extra_pos="after_mfma"))]
 
 src = '''// GENERATED by scripts/gen_ubench_tile.py — do not edit.
 #include <hip/hip_runtime.h>

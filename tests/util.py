@@ -248,8 +248,8 @@ X64_REC = 10240
 
 def retile_q8_1_x64(q_mmq, batch, k, t):
     """block_q8_1_mmq bytes (index (k/128)*batch + token) -> the x64 layout of ggq_quantize_q8_1_x64, built in numpy from the layout's
-    definition (include/ggq.h): per (k/256, token/32) a 10240-byte record { frag[8 groups][2 K-halves][32 tokens][16]; d8[8 groups][h][qd][e]
-    (fp16 for the need_sum formats, else fp32; token 8 qd + 4 h + e); fp16 s8[2 kh][32 tokens][8] at byte 9216 (need_sum formats) };
+    definition (include/ggq.h): per (k/256, token/32) a 10240-byte record { frag[8 groups][2 K-halves][32 tokens][16]; float d8[8 groups][h][qd][e]
+    (the fp16 d as fp32 for the need_sum formats, else the fp32 d; token 8 qd + 4 h + e); fp16 s8[2 kh][32 tokens][8] at byte 9216 (need_sum formats) };
     the token tiles of one K step are contiguous and padded to an even count.  Returns (records, mask of the bytes the layout defines)."""
     from ggq.formats import GGMLType as G
     need_sum = G(int(t)) in (G.Q4_0, G.Q4_1, G.Q5_1, G.Q4_K, G.Q5_K)
@@ -270,9 +270,9 @@ def retile_q8_1_x64(q_mmq, batch, k, t):
                 out[:, tt, o:o + 16] = qs[:, g8, kh]
                 mask[:, tt, o:o + 16] = True
             if need_sum:
-                o = 8192 + g8 * 64 + idx * 2
-                out[:, tt, o:o + 2] = ds[:, g8, 0:2]
-                mask[:, tt, o:o + 2] = True
+                o = 8192 + g8 * 128 + idx * 4
+                out[:, tt, o:o + 4] = np.ascontiguousarray(ds[:, g8, 0:2]).view(np.float16).astype(np.float32).view(np.uint8)
+                mask[:, tt, o:o + 4] = True
                 j = g8 & 3
                 p0 = (j >> 1) * 4 + (j & 1)
                 for p in (p0, p0 + 2):
