@@ -52,8 +52,16 @@ Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 = 12, 13, 14, 2, 8
 NAMES = {Q4_K: "Q4_K", Q4_0: "Q4_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q6_K: "Q6_K"}
 K_DIM, N_DIM, BATCH = 4096, 11008, 128
 COLD_BYTES = 352 << 20   # distinct bytes a "cold" ring must span: 256 MiB Infinity Cache + 32 MiB L2 + margin
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
-ROOFLINE_KERNEL = "ggq::mmq_stream_kernel<Q4_K,f16,TB=2>"
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")
+ROOFLINE_KERNEL = "ggq::mmq_x64_kernel<Q4_K,f16,KS=4>"
+KERNEL_SOURCES = ("mmq_x64.hip", "mmq_x64_loops.inc")   # the traffic figure is refused when these changed since it was measured
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "ggml-libtorch_amd", "csrc", "hip", f), "rb").read())
+    return h.hexdigest()
 MAX_LINE_BYTES = 4096    # the driver reads the LAST stdout line; r03's 21.7 KB line did not parse (BENCH_r03.json parsed: null)
 EXTRA_JSON = "bench_extra.json"
 
@@ -623,24 +631,24 @@ def main():
         # ---- roofline of the dominant kernel (mul_mat_q alone, activations pre-quantised), cold weights ----
         # (the fused op quantises into the fragment-major scratch and runs the streamed kernel for Q4_K:
         #  time exactly that kernel, through the exported pre-quantised entry point)
-        rc = L.ggq_quantize_q8_1_tiled(vp(x), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
+        assert L.ggq_mmq_route(Q4_K, BATCH, K_DIM, N_DIM) == 5, "the headline shape is expected on the 64 x 64 wave-tile kernel (GGQ_MMQ_ROUTE_X64)"
+        rc = L.ggq_quantize_q8_1_x64(vp(x), 1, vp(scratch), BATCH, K_DIM, Q4_K, cur_stream())
         assert rc == 0
 
         def mmq_only(i, ring=w_ring):
-            L.ggq_mul_mat_q_pretiled(vp(ring[i % len(ring)]), vp(scratch), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, cur_stream())
+            L.ggq_mul_mat_q_x64(vp(ring[i % len(ring)]), vp(scratch), vp(y), Q4_K, 1, BATCH, K_DIM, N_DIM, N_DIM, 0, None, cur_stream())
 
         st_cold = time_launches(mmq_only, 208, use_graph=not args.eager)
         st_warm = time_launches(lambda i: mmq_only(i, [w]), 208, use_graph=not args.eager)
         achieved = bytes_per_step / (st_cold["us"] * 1e-6) / 1e9
         ops = 2.0 * BATCH * N_DIM * K_DIM
-        traffic, traffic_note = None, "profiles/r03_traffic.json absent"
+        traffic, traffic_note = None, "profiles/r04_traffic.json absent"
         try:   # PMC-derived HBM bytes per launch, measured offline with rocprofv3 (profiles/); refused when the kernel changed since
             tj = json.load(open(TRAFFIC_JSON))
-            src = hashlib.sha256(open(os.path.join(ROOT, "ggml-libtorch_amd", "csrc", "hip", "mmq.hip"), "rb").read()).hexdigest()
-            if tj.get("mmq_hip_sha256") == src:
+            if tj.get("kernel_source_sha256") == kernel_source_sha():
                 traffic, traffic_note = tj["mmq_q4_k_batch128"]["hbm_bytes_per_launch"], tj["mmq_q4_k_batch128"].get("how", "")
             else:
-                traffic_note = "profiles/r03_traffic.json was measured on a different mmq.hip (sha mismatch): stale, not reported"
+                traffic_note = "profiles/r04_traffic.json was measured on different kernel sources (sha mismatch): stale, not reported"
         except Exception:
             pass
         # `frac` prices the kernel against the HBM roof (the metric is GB/s + % of the HBM roofline) although at batch 128 it

@@ -105,6 +105,11 @@ extern "C" int ggq_mmq_x64_type_supported(int type) {
     default: return 0;
   }
 }
+extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
+  const int64_t units = ((n_rows + 63) / 64) * ((batch + 63) / 64);
+  return units <= 256 && k >= 8 * 256 ? 8 : 4;
+}
+
 extern "C" int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch) {
   if (!ggq_mmq_x64_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
   if ((uint64_t)((batch + 63) / 64 * 2) * (uint64_t)(k / 256) * 10240 >= (1ull << 32)) return 0;   // 32-bit byte offsets into the scratch
@@ -234,6 +239,15 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   if (t16_to > 0 && t16_from == 2 && n_rows < 8192) t16_from = 1;
   const bool t16_shape_ok = (type != GGQ_TYPE_Q6_K && type != GGQ_TYPE_Q3_K) || (n_rows * ggq_row_bytes(type, k) >= 1024 && n_rows * ggq_row_bytes(type, k) < (1ll << 32));   // ggq_mul_mat_q_t16's own guards
   if (t16_shape_ok && ggq_mmq_t16_supported(type, k, batch) && batch >= t16_from && batch <= t16_to) return GGQ_MMQ_ROUTE_T16;
+  // From 33 tokens: the 64 x 64 wave-tile kernel (mmq_x64.hip) wherever its launch has enough units.  Its time goes with
+  // ceil(units / 512) resident rounds of (K / 256) / 4 super-blocks per wave plus a fixed 9 - 10 us (first stage from HBM, K-slice
+  // reduction, write-back, the quantise launch), the streamed kernel's with its 32 x 32/64-token units per CU: measured
+  // (scripts/sweep_x64.py, profiles/r04_x64_vs_stream_q4k_ks4.txt, eleven shapes 2048 x 4096 ... 28672 x 8192, batch 33 ... 1024, op us cold,
+  // streamed / x64) the ratio is 0.63 - 0.88 below 130 units (the x64 launch leaves most CUs empty while every unit pays the fixed part),
+  // 1.04 - 1.23 at 168 - 192 units and 1.2 - 1.45 from 256 units on at every shape and K — one threshold on the unit count:
+  //   11008 x 4096: b64 24.5 / 21.1   b128 31.2 / 29.4   b256 54.3 / 44.3   b1024 193 / 151      4096 x 4096: b128 17.1 / 20.3   b192 25.0 / 20.8
+  //   4096 x 11008: b128 33.7 / 43.2   b192 53.4 / 43.9      3584 x 8192: b128 26.2 / 33.3   b192 41.9 / 34.2      28672 x 8192: b128 127 / 100
+  if (batch >= 33 && ggq_mmq_x64_supported(type, k, batch) && ((n_rows + 63) / 64) * ((batch + 63) / 64) >= 160) return GGQ_MMQ_ROUTE_X64;
   // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):
   // the dot4 kernel while it beats the streamed one with the weights coming from HBM, the barrier-coupled LDS-tile
   // kernel for the mid batches of the two formats whose streamed instance is bound by its weight copy, streamed beyond.

@@ -1487,6 +1487,11 @@ extern "C" int ggq_mul_mat_q_ld(const void* w, const void* x, void* y, int type,
       if (rc != GGQ_OK) return rc;
       return ggq_mul_mat_q_t16(w, scratch, y, type, dtype, batch, k, n_rows, ldy, GGQ_EPI_NONE, nullptr, stream);
     }
+    case GGQ_MMQ_ROUTE_X64: {
+      const int rc = ggq_quantize_q8_1_x64(x, dtype, scratch, batch, k, type, stream);
+      if (rc != GGQ_OK) return rc;
+      return ggq_mul_mat_q_x64(w, scratch, y, type, dtype, batch, k, n_rows, ldy, GGQ_EPI_NONE, nullptr, stream);
+    }
     case GGQ_MMQ_ROUTE_STREAM: {
       const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
       if (rc != GGQ_OK) return rc;
@@ -1503,10 +1508,16 @@ extern "C" int ggq_mul_mat_q_epi(const void* w, const void* x, void* y, int type
                                  int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* scratch,
                                  void* stream) {
   if (!scratch) return GGQ_ERR_ARG;
-  if (ggq_mmq_route(type, batch, k, n_rows) == GGQ_MMQ_ROUTE_T16) {
+  const int route = ggq_mmq_route(type, batch, k, n_rows);
+  if (route == GGQ_MMQ_ROUTE_T16) {
     const int rc = ggq_quantize_q8_1_t16(x, dtype, scratch, batch, k, type, stream);
     if (rc != GGQ_OK) return rc;
     return ggq_mul_mat_q_t16(w, scratch, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream);
+  }
+  if (route == GGQ_MMQ_ROUTE_X64) {
+    const int rc = ggq_quantize_q8_1_x64(x, dtype, scratch, batch, k, type, stream);
+    if (rc != GGQ_OK) return rc;
+    return ggq_mul_mat_q_x64(w, scratch, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream);
   }
   if (!ggq_mmq_tiled_supported(type, k)) return ggq_mmq_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
   const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);

@@ -49,10 +49,12 @@ __device__ __forceinline__ float x64_apply_epilogue(float v, int epi, const void
 constexpr int X64_REC = 10240;          // bytes of one (super-block, 32-token tile) record of the x64 scratch layout
 constexpr int X64_STAGE = 64 * 144;     // Q4_K: one ring stage = 64 rows x one super-block
 constexpr int X64_WAVE_LDS = 2 * X64_STAGE + 2048;   // a wave's weight ring + the fp32 token scales of its two token tiles for one K step
-constexpr int X64_LDS = 4 * X64_WAVE_LDS;            // 80 KB: two workgroups fill a CU's 160 KB exactly; the K-slice reduction (64 KB) aliases it
+// four K-slices: 80 KB, two workgroups fill a CU's 160 KB exactly; eight K-slices (few units: one workgroup per CU, half the K loop per
+// wave): all 160 KB.  The K-slice reduction (16 KB per slice) aliases the rings.
+template <int KS> struct X64Lds { static constexpr int BYTES = KS * X64_WAVE_LDS; };
 
-template <int T, int DT>
-__global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
+template <int T, int DT, int KS>
+__global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
                                                          void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
                                                          int n_tok_tiles, int n_units, int per_xcd, int epi,
                                                          const void* __restrict__ aux) {
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restri
   const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int n_sb = k / 256;
-  const int sb_begin = (int)((int64_t)ks * n_sb / 4), sb_end = (int)((int64_t)(ks + 1) * n_sb / 4);
+  const int sb_begin = (int)((int64_t)ks * n_sb / KS), sb_end = (int)((int64_t)(ks + 1) * n_sb / KS);
   const uint32_t row_bytes = (uint32_t)n_sb * Fmt<T>::BS;
   const int valid_rows = min(64, n_rows - n0);
 
@@ -105,20 +107,21 @@ __global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restri
   __syncthreads();
   // thread -> (token tl64 of the unit, 16 consecutive rows): lane (row r, half h) of tile (rt, tt) holds token 32 tt + 8 (i >> 2) + 4 h + (i & 3)
   // of row 32 rt + r in register i, so four consecutive rows of one token are four consecutive floats of red[]
-  const int tl64 = tid >> 2, rb = (tid & 3) * 16;
+  constexpr int RPT = 4096 / (64 * KS);   // rows per thread: 16 (four waves) or 8 (eight)
+  const int tl64 = tid / (64 / RPT), rb = (tid % (64 / RPT)) * RPT;
   const int t = t0 + tl64;
   if (t >= batch) return;
   const int tt = tl64 >> 5, tl = tl64 & 31;
   const int i_reg = 4 * (tl >> 3) + (tl & 3), hh = (tl >> 2) & 1;
-  float v[16];
+  float v[RPT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < RPT / 4; ++j) {
     const int R = rb + 4 * j, rt = R >> 5, rr = R & 31;
     v4f s = *(const v4f*)(red + (((0 * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
 #pragma unroll
-    for (int sl = 1; sl < 4; ++sl) {
+    for (int sl = 1; sl < KS; ++sl) {
       const v4f p = *(const v4f*)(red + (((sl * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
-      s += p;   // fixed slice order ((0 + 1) + 2) + 3
+      s += p;   // fixed slice order ((0 + 1) + 2) + 3 ...
     }
     v[4 * j] = s[0]; v[4 * j + 1] = s[1]; v[4 * j + 2] = s[2]; v[4 * j + 3] = s[3];
   }
@@ -126,14 +129,14 @@ __global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restri
   const int64_t yi0 = (int64_t)t * ldy + row0;
   if (epi != GGQ_EPI_NONE) {   // wave-uniform
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int e = 0; e < RPT; ++e)
       if (row0 + e < n_rows) v[e] = x64_apply_epilogue<DT>(v[e], epi, aux, yi0 + e, row0 + e);
   }
-  const bool vec_ok = DT != GGQ_F32 && (ldy & 7) == 0 && ((uintptr_t)y & 15) == 0 && row0 + 16 <= n_rows;
+  const bool vec_ok = DT != GGQ_F32 && (ldy & 7) == 0 && ((uintptr_t)y & 15) == 0 && row0 + RPT <= n_rows;
   if (vec_ok) {
-    uint32_t pk[8];
+    uint32_t pk[RPT / 2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < RPT / 2; ++e) {
       uint16_t lo, hi;
       if (DT == GGQ_F16) {
         lo = __builtin_bit_cast(uint16_t, (_Float16)v[2 * e]);
@@ -146,10 +149,10 @@ __global__ void __launch_bounds__(256, 2) mmq_x64_kernel(const uint8_t* __restri
     }
     v4i* dst = (v4i*)((uint16_t*)y + yi0);
     dst[0] = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-    dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
+    if constexpr (RPT == 16) dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
   } else {
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int e = 0; e < RPT; ++e)
       if (row0 + e < n_rows) Elem<DT>::st(y, yi0 + e, v[e]);
   }
 }
@@ -160,12 +163,24 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
   const int64_t n_tok_tiles = (batch + 63) / 64;
   const int64_t n_units = ((n + 63) / 64) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
-  auto kern = mmq_x64_kernel<T, DT>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64_LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
   const int64_t per_xcd = (n_units + 7) / 8;
-  GGQ_HIP_PRE_LAUNCH();
-  hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), X64_LDS, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                     (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+  // at most one unit per CU: eight K-slices per unit (two waves per SIMD either way, half the K loop per wave); otherwise four, two
+  // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable)
+  static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");   // -DGGQ_TUNING builds only (scripts/sweep_x64.py): force 4 or 8
+  const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : ggq_mmq_x64_k_slices(batch, k, n);
+  if (ks == 8 && k >= 8 * 256) {
+    auto kern = mmq_x64_kernel<T, DT, 8>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<8>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
+    GGQ_HIP_PRE_LAUNCH();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64Lds<8>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
+                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+  } else {
+    auto kern = mmq_x64_kernel<T, DT, 4>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<4>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
+    GGQ_HIP_PRE_LAUNCH();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), X64Lds<4>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
+                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+  }
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }

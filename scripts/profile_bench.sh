@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage (on the GPU box): scripts/profile_bench.sh TAG — the round's judged profiles:
 #   1. rocprofv3 --kernel-trace --stats over the same command as the bench line (python3 bench.py --steps 200 --no-extra)
-#   2. FETCH_SIZE and WRITE_SIZE of the streamed Q4_K kernel, separate --pmc passes (MI355X_MICROARCH.md, HBM section)
+#   2. FETCH_SIZE and WRITE_SIZE of the headline Q4_K kernel (mmq_x64_kernel), separate --pmc passes (MI355X_MICROARCH.md, HBM section)
 # summaries land in gpurun_out/prof_TAG_*; copy what is judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python3 $R/bench.py --steps 200 --warmup 20 --no-extra > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}_stats.log || echo "stats pass failed"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_$C -- python3 $R/scripts/run_kernel.py mmq 12 128 8 > $R/gpurun_out/prof_${TAG}_$C.log 2>&1 || echo "$C pass failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/prof_${TAG}_$C -- python3 $R/scripts/run_kernel.py x64 12 128 8 > $R/gpurun_out/prof_${TAG}_$C.log 2>&1 || echo "$C pass failed"
 done
 python3 - <<PY
 import csv, glob, json, hashlib, collections
@@ -23,16 +23,19 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = []
     for f in glob.glob(R + "/gpurun_out/prof_%s_%s/**/*counter_collection.csv" % (TAG, C), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "mmq_stream_kernel" in r["Kernel_Name"] and r["Counter_Name"] == C: acc.append(float(r["Counter_Value"]))
+            if "mmq_x64_kernel" in r["Kernel_Name"] and r["Counter_Name"] == C: acc.append(float(r["Counter_Value"]))
     vals[C] = acc
     print(C, "n", len(acc), "mean", sum(acc) / max(1, len(acc)))
 if vals["FETCH_SIZE"] and vals["WRITE_SIZE"]:
     # units: FETCH_SIZE / WRITE_SIZE are in KiB? rocprofv3 reports them in kilobytes of 1024 bytes per the counter definition;
     # gfx950 correction (MI355X_MICROARCH.md): FETCH_SIZE counts half of a wide coalesced streaming read -> doubled
     f = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]); w = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
-    out = {"mmq_hip_sha256": hashlib.sha256(open(R + "/ggml-libtorch_amd/csrc/hip/mmq.hip", "rb").read()).hexdigest(),
+    h = hashlib.sha256()
+    for fn in ("mmq_x64.hip", "mmq_x64_loops.inc"):
+        h.update(open(R + "/ggml-libtorch_amd/csrc/hip/" + fn, "rb").read())
+    out = {"kernel_source_sha256": h.hexdigest(),
            "mmq_q4_k_batch128": {"FETCH_SIZE_raw": f, "WRITE_SIZE_raw": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
-                                 "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, 8 launches of scripts/run_kernel.py mmq 12 128, warm weights), counter unit KiB, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 read correction of MI355X_MICROARCH.md)"}}
+                                 "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, 8 launches of scripts/run_kernel.py x64 12 128, warm weights), counter unit KiB, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 read correction of MI355X_MICROARCH.md)"}}
     json.dump(out, open(R + "/gpurun_out/prof_%s_traffic.json" % TAG, "w"), indent=1)
     print(json.dumps(out["mmq_q4_k_batch128"]))
 PY

@@ -58,7 +58,8 @@ def test_mmq_routing_table():
     and consistent with what each kernel supports.  Host-only: the CPU library exports the same function."""
     from ggq import lib as ggqlib
     L = ggqlib.cpu()
-    NONE, DOT4, LDS_TILE, STREAM, T16 = range(5)
+    NONE, DOT4, LDS_TILE, STREAM, T16, X64 = range(6)
+    units64 = lambda b, n: -(-n // 64) * -(-b // 64)
     Q4_K, Q5_K, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q6_K, Q3_K = 12, 13, 2, 3, 6, 7, 8, 14, 11
     shapes = [(4096, 11008), (11008, 4096), (8192, 3584), (8192, 28672), (256, 16), (4096 + 32, 64)]
     for k, n in shapes:
@@ -69,7 +70,11 @@ def test_mmq_routing_table():
                 if k % BLOCK[t][0]:
                     assert r == NONE
                     continue
-                assert r in (DOT4, LDS_TILE, STREAM, T16)
+                assert r in (DOT4, LDS_TILE, STREAM, T16, X64)
+                if r == X64:   # the 64 x 64 wave tiles: from 33 tokens, where the launch has at least 160 units, for the formats the kernel serves
+                    assert b >= 33 and k % 256 == 0 and units64(b, n) >= 160 and L.ggq_mmq_x64_supported(int(t), k, b) == 1
+                elif b >= 33 and k % 256 == 0 and units64(b, n) >= 160:
+                    assert L.ggq_mmq_x64_supported(int(t), k, b) == 0
                 if r == T16:
                     assert k % 256 == 0 and (1 if n < 8192 else 2) <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
                 if r == DOT4:
@@ -82,8 +87,9 @@ def test_mmq_routing_table():
         # two token tiles per wave (batch 17 - 32): up to 4096 rows, or where the streamed launch would leave a third of its CU-rounds empty
         two = T16 if n in (11008, 4096, 3584) else STREAM
         assert L.ggq_mmq_route(Q4_K, 32, k, n) == two and L.ggq_mmq_route(Q5_K, 17, k, n) == two
-        assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16) and L.ggq_mmq_route(Q4_K, 33, k, n) == STREAM
-        assert L.ggq_mmq_route(Q4_K, 128, k, n) == STREAM
+        assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
+        assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if n >= 64 * 160 else STREAM)
+        assert L.ggq_mmq_route(Q4_K, 128, k, n) == (X64 if n >= 64 * 80 else STREAM) and L.ggq_mmq_route(Q4_K, 4096, k, n) == X64
         mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows
         assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
@@ -195,3 +201,30 @@ def test_bench_line_is_compact_and_round_trips():
     # an over-long config must still give a parseable line (optional parts are dropped, never the contract keys)
     out2 = dict(out, config=dict(out["config"], workload="x" * 1500))
     assert len(bench.compact_line(out2, detail)) <= bench.MAX_LINE_BYTES
+
+
+def test_route_regret_on_the_committed_sweep():
+    """ggq_mmq_route against the measured sweep it was written from (profiles/r04_x64_vs_stream_q4k_ks4.txt: Q4_K, eleven shapes incl.
+    K = 4096 / 8192 / 11008, batch 33 ... 1024, op = quantise + kernel, cold; "current route" there = the streamed kernel): at every
+    measured point the kernel the route picks is within 10 % of the faster of the two — the regret bound the round-3 review asked
+    for in place of further audit passes."""
+    import re
+    from ggq import lib as ggqlib
+    L = ggqlib.cpu()
+    STREAM, X64 = 3, 5
+    pts = 0
+    worst = 0.0
+    for line in open(os.path.join(ROOT, "profiles", "r04_x64_vs_stream_q4k_ks4.txt")):
+        m = re.match(r"\s*(\d+) x\s*(\d+) batch\s*(\d+): route 3\s+([\d.]+) /\s*([\d.]+) \|\s*([\d.]+) /\s*([\d.]+)", line)
+        if not m:
+            continue
+        n, k, b = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        stream_cold, x64_cold = float(m.group(5)), float(m.group(7))
+        r = L.ggq_mmq_route(12, b, k, n)
+        assert r in (STREAM, X64), (n, k, b, r)
+        chosen = x64_cold if r == X64 else stream_cold
+        regret = chosen / min(stream_cold, x64_cold) - 1.0
+        worst = max(worst, regret)
+        assert regret <= 0.10, f"{n} x {k} batch {b}: route {r} takes {chosen} us, the other kernel {min(stream_cold, x64_cold)} us"
+        pts += 1
+    assert pts >= 90, pts
