@@ -47,7 +47,7 @@ __device__ __forceinline__ float x64_apply_epilogue(float v, int epi, const void
 }
 
 constexpr int X64_REC = 10240;          // bytes of one (super-block, 32-token tile) record of the x64 scratch layout
-constexpr int X64_STAGE = 64 * 144;     // Q4_K: one ring stage = 64 rows x one super-block
+constexpr int X64_STAGE = 64 * 144;     // one ring stage = 64 rows at a 144-byte pitch: a Q4_K super-block, or 128 elements of Q8_0 (136 bytes + 8 of overrun)
 constexpr int X64_WAVE_LDS = 2 * X64_STAGE + 2048;   // a wave's weight ring + the fp32 token scales of its two token tiles for one K step
 // four K-slices: 80 KB, two workgroups fill a CU's 160 KB exactly; eight K-slices (few units: one workgroup per CU, half the K loop per
 // wave): all 160 KB.  The K-slice reduction (16 KB per slice) aliases the rings.
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __re
   const int r = lane & 31, h = lane >> 5;
   const int n_sb = k / 256;
   const int sb_begin = (int)((int64_t)ks * n_sb / KS), sb_end = (int)((int64_t)(ks + 1) * n_sb / KS);
-  const uint32_t row_bytes = (uint32_t)n_sb * Fmt<T>::BS;
+  const uint32_t row_bytes = (uint32_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
   const int valid_rows = min(64, n_rows - n0);
 
   v32f acc0, acc1;
@@ -87,13 +87,20 @@ __global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __re
     const uint32_t sbstride = n_tt32 * X64_REC;
     const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
     const uint32_t ring = (uint32_t)(uintptr_t)lds + (uint32_t)ks * X64_WAVE_LDS;
-    const uint32_t hoff = 16u + 16u * (uint32_t)h;
     // LDS-DMA source offset of this lane inside the seven rows one instruction copies: row lane / 9, 16-byte chunk lane % 9
     // (lane 63 = chunk 0 of the next instruction's first row: both write the same bytes)
     const uint32_t dmaoff = (uint32_t)(lane / 9) * row_bytes + (uint32_t)(lane % 9) * 16u;
-    x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, ring + 2 * X64_STAGE + (uint32_t)h * 64u, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff,
-                 wrsrc, arsrc, ring, (uint32_t)(sb_end - sb_begin), sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0,
-                 f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+    const uint32_t ldsd = ring + 2 * X64_STAGE + (uint32_t)h * 64u;
+    const uint32_t nsb = (uint32_t)(sb_end - sb_begin);
+    if constexpr (T == GGQ_TYPE_Q8_0) {   // 272 bytes of a row per 256 elements, in two 128-element stages at a 144-byte LDS pitch
+      const uint32_t hoff = 16u * (uint32_t)h;
+      x64_loop_q80(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                   sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+    } else {
+      const uint32_t hoff = 16u + 16u * (uint32_t)h;
+      x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                   sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+    }
   }
 
   // ---- K-slice reduction: red[slice][tile][register][lane]; the rings are dead once every wave is past its last ds_read ----
@@ -213,6 +220,7 @@ extern "C" int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type
   const X64Epilogue ep{epilogue, aux};
   switch (type) {
     case GGQ_TYPE_Q4_K: return launch_x64_dt<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
+    case GGQ_TYPE_Q8_0: return launch_x64_dt<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     default: return GGQ_ERR_TYPE;
   }
 }

@@ -115,7 +115,22 @@ class Q4K:
     STAGE = ROWS * 144
 
 
+class Q80:
+    """Q8_0: 34-byte blocks {fp16 d; int8 qs[32]}.  One ring stage = 128 elements = 136 bytes of a row, copied at a 144-byte pitch (the
+    ninth 16-byte chunk runs 8 bytes into the next stage: never read), so the row-major LDS-DMA scheme and the conflict-free pitch of
+    Q4_K carry over.  The int8 MFMA operand is the raw quant bytes: lane (row, h) needs bytes 34 g + 2 + 16 h .. + 15 of its row's stage,
+    which two ALIGNED ds_read_b128 cover; v_alignbyte_b32 / v_mov_b32 move them into place (a misaligned ds_read_b128 costs 3.4 x)."""
+    name, type_id = "q80", 8
+    BS = 136
+    CPR, DIV = 9, 7282
+    N_DMA = 10
+    STAGE = ROWS * 144
+
+
 F = Q4K
+RAW8 = (192, 200)           # Q8_0: two aligned 16-byte chunks of the row's stage per row tile (the Q4_K header / min-term registers are free)
+DREG = ((208, 209), (210, 211))   # Q8_0: the block's fp16 d, [row tile][group parity]
+S_RUNA, S_RUNB, S_NEXTW = 75, 76, 77   # Q8_0: running source offsets of the two stage copies, byte step to the next 256 elements
 
 
 def mfma(a, g, ti):
@@ -470,12 +485,159 @@ def gen(label):
     return a
 
 
+def q80_reads(a, rt, g):
+    """the two aligned chunks that hold group g's quant bytes of this lane's row and K half, and the block's d (g = 8, 9: groups 0, 1 of
+    the next 256 elements; stage buffer = (g >> 2) & 1)"""
+    buf, gl = (g >> 2) & 1, g & 3
+    base = buf * F.STAGE + rt * 32 * 144
+    a.lds(f"ds_read_b128 {vr(RAW8[rt], 4)}, {vr(V_LDSW)} offset:{base + 32 * gl}", f"raw{rt}x")
+    a.lds(f"ds_read_b128 {vr(RAW8[rt] + 4, 4)}, {vr(V_LDSW)} offset:{base + 32 * gl + 16}", f"raw{rt}")
+    a.lds(f"ds_read_u16 {vr(DREG[rt][g & 1])}, {vr(V_LDSHN)} offset:{base + 34 * gl}", f"d{rt}_{g & 1}")
+
+
+def q80_w_prep(a, rt, g):
+    """int8 operand of group g from the chunk pair: the quant bytes start 2 (g & 3) + 2 bytes into it"""
+    a.wait_lg(f"raw{rt}")
+    sh = 2 * (g & 3) + 2
+    d0, rem = sh // 4, sh % 4
+    for i in range(4):
+        if rem:
+            a.i(f"v_alignbyte_b32 {vr(WOP[rt] + i)}, {vr(RAW8[rt] + i + d0 + 1)}, {vr(RAW8[rt] + i + d0)}, {rem}")
+        else:
+            a.i(f"v_mov_b32 {vr(WOP[rt] + i)}, {vr(RAW8[rt] + i + d0)}")
+
+
+def q80_dw_prep(a, rt, g):
+    """row scale of group g: dw = d (fp16 -> fp32), nm = -12582912 * dw, as duplicated pairs"""
+    p = g & 1
+    a.wait_lg(f"d{rt}_{p}")
+    a.i(f"v_cvt_f32_f16_e32 {vr(DWNM[rt] + 4 * p)}, {vr(DREG[rt][p])}")
+    a.i(f"v_cvt_f32_f16_e32 {vr(DWNM[rt] + 4 * p + 1)}, {vr(DREG[rt][p])}")
+    a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 4 * p + 2, 2)}, {vr(DWNM[rt] + 4 * p, 2)}, {sr(S_NEGM, 2)}")
+
+
+def q80_dma(a, j, buf, s_run, tag):
+    """LDS-DMA instruction j (rows 7 j .. 7 j + 6) of the copy into stage buffer `buf`; s_run = its running source offset"""
+    if j:
+        a.i(f"s_add_u32 {sr(s_run)}, {sr(s_run)}, {sr(S_RB7)}")
+    a.i(f"s_add_u32 m0, {sr(S_LDS)}, {buf * F.STAGE + 16 * 7 * F.CPR * j}")
+    if j == F.N_DMA - 1:
+        a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
+        a.i(f"s_mov_b64 exec, {hex((1 << (F.CPR * (ROWS - 7 * j))) - 1)}")
+    else:
+        a.i("s_nop 0")
+    a.vmem(f"buffer_load_dwordx4 {vr(V_DMAOFF)}, {sr(S_WRSRC, 4)}, {sr(s_run)} offen lds", tag)
+    if j == F.N_DMA - 1:
+        a.i(f"s_mov_b64 exec, {sr(S_EXEC, 2)}")
+
+
+def gen_q80(label):
+    """Q8_0: 256 elements per loop iteration = two 128-element stages in FIXED buffers (A: groups 0-3, B: groups 4-7); A of the next
+    iteration is requested in groups 3-4 (after this one's last read of A), B of the next one in group 7 + the next iteration's first
+    slots.  No header, no min term: the block's d comes with the quant bytes."""
+    global F
+    F = Q80
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")  # row base of this lane (hoff = 16 h): where the block headers are read
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
+    a.i(f"s_mov_b32 {sr(S_RUNA)}, {sr(S_WK)}")
+    for j in range(F.N_DMA):
+        q80_dma(a, j, 0, S_RUNA, "dmaA")
+    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    d8_dma(a, 0, 0, False)
+    d8_dma(a, 1, 0, False)
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[1] + k)}, 0")
+    for k in range(8):
+        a.i(f"v_mov_b32 {vr(DWNM[1] + k)}, 0")
+    act_loads(a, 0)
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
+    for j in range(8):
+        q80_dma(a, j, 1, S_RUNB, "dmaB")                          # (the last two: in the loop's first slots, as in every iteration)
+    a.wait_vm("dmaA")
+    a.wait_vm("d8dma0_1")
+    q80_reads(a, 0, 0)
+    q80_reads(a, 1, 0)
+    q80_w_prep(a, 0, 0)
+    q80_reads(a, 0, 1)
+    d8_reads(a, 0, 0)
+    q80_w_prep(a, 1, 0)
+    q80_reads(a, 1, 1)
+    # (d of group 0 is in DREG[.][0] — waited for by the first dw_prep; reads in flight: group 1's, token tile 0's scales)
+    a.i(f"L_sb_{label}%=:")
+    vm0, lg0 = list(a.vm), list(a.lg)
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
+    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {2 * F.BS}")
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
+    for g in range(8):
+        for ti in range(4):
+            rt = ti & 1
+            mfma(a, g, ti)
+            if ti < 2:
+                q80_dw_prep(a, ti, g)
+            if ti == 0:
+                act_loads(a, (g + 1) & 1)
+                advance_offsets(a, g)
+            if ti >= 2:
+                if (g, ti) == (2, 2):
+                    a.wait_vm("dmaB")            # groups 4-7 of this iteration have landed: group 4's chunks are read below
+                if (g, ti) == (6, 2):
+                    a.wait_vm("dmaA")            # ... groups 0-3 of the next one
+                q80_w_prep(a, rt, g + 1)
+                q80_reads(a, rt, g + 2)
+            # stage copies: B of this iteration's last two instructions, A of the next one in groups 3 / 4, B of the next one in group 7
+            if g == 0 and ti < 2:
+                q80_dma(a, 8 + ti, 1, S_RUNB, "dmaB")
+            if g == 3 or (g == 4 and ti < 2):
+                for j in ((2 * ti, 2 * ti + 1) if g == 3 else (8 + ti,)):
+                    if j == 0:
+                        a.i(f"s_add_u32 {sr(S_RUNA)}, {sr(S_WK)}, {sr(S_NEXTW)}")
+                    q80_dma(a, j, 0, S_RUNA, "dmaA")
+            if g == 7:
+                for j in (2 * ti, 2 * ti + 1):
+                    if j == 0:
+                        a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_WK)}, {sr(S_NEXTW)}")
+                        a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_RUNB)}, {F.BS}")
+                    q80_dma(a, j, 1, S_RUNB, "dmaB")
+            if g == 0 and ti >= 2:
+                d8_dma(a, ti - 2, 1, False)
+            if (g, ti) == (3, 2):
+                d8_dma(a, 0, 0, True)
+            if (g, ti) == (4, 0):
+                d8_dma(a, 1, 0, True)
+            pg, pti = (g, ti - 1) if ti else ((g - 1) % 8, 3)
+            fma_block(a, pg, pti)
+            if pti == 1:
+                d8_reads(a, 0, (pg + 1) % 8)
+            if pti == 3:
+                d8_reads(a, 1, (pg + 1) % 8)
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {2 * F.BS}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    fma_block(a, 7, 3)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    F = Q4K
+    return a
+
+
 def emit(a, fn_name):
     asm = "\n".join(f'      "{l}\\n"' for l in a.lines)
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
     clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
     s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1,
-             S_EXEC, S_EXEC + 1, S_NEXT}
+             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW}
     clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
     return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
 static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,
@@ -496,8 +658,10 @@ static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v
 
 if __name__ == "__main__":
     a = gen("q4k")
+    b = gen_q80("q80")
     if "--list" in sys.argv:
-        print("\n".join(a.lines))
+        print("\n".join((b if "q80" in sys.argv else a).lines))
     with open(os.environ.get("X64_OUT", OUT), "w") as f:
         f.write(emit(a, "x64_loop_q4k"))
-    print(len(a.lines), "instructions ->", OUT, file=sys.stderr)
+        f.write(emit(b, "x64_loop_q80"))
+    print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)
