@@ -90,8 +90,10 @@ def test_mmq_routing_table():
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if n >= 64 * 160 else STREAM)
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == (X64 if n >= 64 * 80 else STREAM) and L.ggq_mmq_route(Q4_K, 4096, k, n) == X64
-        mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows
-        assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 65, k, n) == STREAM
+        mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows ...
+        big = lambda b: X64 if units64(b, n) >= 160 else None   # ... and from 33 tokens the 64 x 64 wave tiles where the launch has 160 units
+        assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == (big(64) or mid8)
+        assert L.ggq_mmq_route(Q8_0, 65, k, n) == (big(65) or STREAM)
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
         assert L.ggq_mmq_route(Q6_K, 16, k, n) == (T16 if n <= 16384 else LDS_TILE)   # its 16-token tiles stop at 16384 rows (batch 9 - 16) / 32768 (to 8)
