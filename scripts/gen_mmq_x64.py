@@ -58,6 +58,7 @@ X_PLAIN2 = int(os.environ.get("X64_PLAIN2", "0"))      # 1: second stage as plai
 X_NOD8 = int(os.environ.get("X64_NOD8", "0"))          # 1: no token-scale loads inside the loop (wrong results; timing experiments only)
 X_NOACT = int(os.environ.get("X64_NOACT", "0"))        # 1: no activation-fragment loads inside the loop (wrong results; timing experiments only)
 X_NOFILL = int(os.environ.get("X64_NOFILL", "0"))      # timing experiments only (wrong results): 1 no dw_prep, 2 no unpack + raw reads, 8 no header decode inside the loop
+X_NOWAIT = int(os.environ.get("X64_NOWAIT", "0"))      # timing experiments only (wrong results): 1 = no vmcnt waits inside the loop, 2 = no lgkmcnt waits, 3 = neither
 X_NODMA = int(os.environ.get("X64_NODMA", "0"))        # 1: no LDS-DMA inside the loop, every super-block re-reads stage 0 (wrong results; determinism experiments only)
 
 
@@ -99,11 +100,19 @@ class Asm:
         self.lines.append(f"s_waitcnt {name}({n})")
         return q[idx + 1:]
 
+    armed = False   # X_NOWAIT experiments: set once the loop body starts
+
     def wait_vm(self, tag):
+        n0 = len(self.lines)
         self.vm = self._wait(self.vm, tag, "vmcnt", 63)
+        if Asm.armed and (X_NOWAIT & 1):
+            del self.lines[n0:]
 
     def wait_lg(self, tag):
+        n0 = len(self.lines)
         self.lg = self._wait(self.lg, tag, "lgkmcnt", 15)
+        if Asm.armed and (X_NOWAIT & 2):
+            del self.lines[n0:]
 
 
 class Q4K:
@@ -373,6 +382,7 @@ def gen(label):
     a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
     # ---------------------------------------------------------------- loop over the super-blocks of the slice
     X_NOACT_ARMED[0] = True
+    Asm.armed = True
     a.i(f"L_sb_{label}%=:")
     # (the s8 loads are the oldest operations in flight: the first vmcnt wait of the body — for act0, younger — covers them, so
     #  they need no entry of their own; the loop body's own s8 loads, issued in group 3, are covered the same way by group 4's waits)
@@ -461,6 +471,8 @@ def gen(label):
     # top-of-loop queue holds beyond that suffix is known complete by then: its waits are satisfied at once)
     assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0, (a.vm, vm0, a.lg, lg0)
     # ---------------------------------------------------------------- epilogue: the FMAs of the last tile, drain
+    Asm.armed = False
+    X_NOACT_ARMED[0] = False
     fma_block(a, 7, 3)
     a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.i("s_nop 7")
