@@ -110,10 +110,20 @@ extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
   return units <= 256 && k >= 8 * 256 ? 8 : 4;
 }
 
+// rows of one unit: 96 (four two-row-tile waves + four one-row-tile waves, one workgroup per CU) where the launch then is ONE round of
+// at most 256 workgroups while 64-row units would put two workgroups on some CUs and one on the others (the two-workgroup CUs finish
+// 40-60 % later: profiles/r04_x64_stamps.txt); Q4_K only (the one-row-tile loop exists for it)
+extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows) {
+  if (type != GGQ_TYPE_Q4_K || k < 4 * 256) return 64;
+  const int64_t tt = (batch + 63) / 64;
+  const int64_t u64 = ((n_rows + 63) / 64) * tt, u96 = ((n_rows + 95) / 96) * tt;
+  return u64 > 256 && u96 <= 256 ? 96 : 64;
+}
+
 extern "C" int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch) {
   if (!ggq_mmq_x64_type_supported(type) || k <= 0 || k % 256 || batch <= 0) return 0;
   if ((uint64_t)((batch + 63) / 64 * 2) * (uint64_t)(k / 256) * 10240 >= (1ull << 32)) return 0;   // 32-bit byte offsets into the scratch
-  if ((uint64_t)ggq_row_bytes(type, k) * 64 >= (1ull << 32)) return 0;                             // ... and inside a 64-row weight tile
+  if ((uint64_t)ggq_row_bytes(type, k) * 64 >= (1ull << 32)) return 0;                             // ... and inside a wave's weight tile (64 rows at most)
   return 1;
 }
 

@@ -35,6 +35,29 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 #include GGQ_X64_LOOPS_INC
 
 struct X64Epilogue { int kind; const void* aux; };
+}  // namespace ggq
+
+#ifndef GGQ_X64_STAMP
+#define GGQ_X64_STAMP 0   // 1: per-wave timestamps (scripts/stamps_x64.py); 0 in every shipped build
+#endif
+#if GGQ_X64_STAMP
+__device__ unsigned long long g_x64_stamps[2048 * 8 * 16];
+extern "C" int ggq_debug_read_x64_stamps(void* dst, long long n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x64_stamps), n * 8);
+}
+// slot i: 100 MHz wall clock; slot 8 + i: the shader clock (s_memtime); slot 7: hardware id (XCC / SE / CU / SIMD)
+#define X64_STAMP(i)                                                                          \
+  do {                                                                                        \
+    if (lane == 0 && blockIdx.x < 2048) {                                                     \
+      g_x64_stamps[(blockIdx.x * 8 + wave) * 16 + (i)] = wall_clock64();                        \
+      g_x64_stamps[(blockIdx.x * 8 + wave) * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime();      \
+    }                                                                                         \
+  } while (0)
+#else
+#define X64_STAMP(i) do {} while (0)
+#endif
+
+namespace ggq {
 
 template <int DT>
 __device__ __forceinline__ float x64_apply_epilogue(float v, int epi, const void* aux, int64_t yi, int row) {
@@ -52,70 +75,109 @@ constexpr int X64_WAVE_LDS = 2 * X64_STAGE + 2048;   // a wave's weight ring + t
 // four K-slices: 80 KB, two workgroups fill a CU's 160 KB exactly; eight K-slices (few units: one workgroup per CU, half the K loop per
 // wave): all 160 KB.  The K-slice reduction (16 KB per slice) aliases the rings.
 template <int KS> struct X64Lds { static constexpr int BYTES = KS * X64_WAVE_LDS; };
+// 96-row units (R3): four waves as above on rows 0-63 + four one-row-tile waves (32 rows x 64 tokens, the same K quarter each) on rows
+// 64-95, one workgroup per CU: a launch of 257 .. 512 units of 64 rows that has at most 256 units of 96 is one even round instead of
+// "some CUs carry two workgroups" (ggq_mmq_x64_unit_rows; profiles/r04_x64_stamps.txt)
+constexpr int X64_STAGE_R1 = 32 * 144;
+constexpr int X64_WAVE_LDS_R1 = 2 * X64_STAGE_R1 + 2048;
+constexpr int X64_LDS_R3 = 4 * X64_WAVE_LDS + 4 * X64_WAVE_LDS_R1;
 
-template <int T, int DT, int KS>
-__global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
+template <int T, int DT, int KS, bool R3>
+__global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
                                                          void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
                                                          int n_tok_tiles, int n_units, int per_xcd, int epi,
                                                          const void* __restrict__ aux) {
+  static_assert(!R3 || (KS == 4 && T == GGQ_TYPE_Q4_K), "96-row units: Q4_K, four K-slices");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
   if (unit >= n_units) return;
+  constexpr int UROWS = R3 ? 96 : 64;
   const int row_tile = unit / n_tok_tiles, tok_tile = unit % n_tok_tiles;
-  const int n0 = row_tile * 64, t0 = tok_tile * 64;
+  const int t0 = tok_tile * 64;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool one_tile = R3 && wave >= 4;                  // the wave kind with one row tile (rows 64-95 of the unit)
+  const int ks = R3 ? (wave & 3) : wave;
+  const int n0 = row_tile * UROWS, nb = n0 + (one_tile ? 64 : 0);
   const int r = lane & 31, h = lane >> 5;
   const int n_sb = k / 256;
   const int sb_begin = (int)((int64_t)ks * n_sb / KS), sb_end = (int)((int64_t)(ks + 1) * n_sb / KS);
   const uint32_t row_bytes = (uint32_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
-  const int valid_rows = min(64, n_rows - n0);
+  const int valid_rows = min(one_tile ? 32 : 64, n_rows - nb);
+  X64_STAMP(0);
+#if GGQ_X64_STAMP
+  if (lane == 0 && blockIdx.x < 2048) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_x64_stamps[(blockIdx.x * 8 + wave) * 16 + 7] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 
   v32f acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 32; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 
-  if (sb_begin < sb_end) {   // wave-uniform
+  if (sb_begin < sb_end && valid_rows > 0) {   // wave-uniform
     v16i magic;
 #pragma unroll
     for (int i = 0; i < 16; ++i) magic[i] = 0x4B400000;
     // weights: the tile's valid rows only — rows past the tensor read as zeros (d = 0: they contribute nothing and are never stored)
     const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(w + (int64_t)n0 * row_bytes), 0, (int)((uint32_t)valid_rows * row_bytes), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(w + (int64_t)nb * row_bytes), 0, (int)((uint32_t)valid_rows * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q8, 0, (int)0xFFFFFFFFu, 0x00020000);
     const uint32_t n_tt32 = 2u * (uint32_t)n_tok_tiles;                  // 32-token records per super-block
     const uint32_t sbstride = n_tt32 * X64_REC;
     const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
-    const uint32_t ring = (uint32_t)(uintptr_t)lds + (uint32_t)ks * X64_WAVE_LDS;
+    const uint32_t ring = (uint32_t)(uintptr_t)lds + (one_tile ? 4u * X64_WAVE_LDS + (uint32_t)ks * X64_WAVE_LDS_R1 : (uint32_t)ks * X64_WAVE_LDS);
     // LDS-DMA source offset of this lane inside the seven rows one instruction copies: row lane / 9, 16-byte chunk lane % 9
     // (lane 63 = chunk 0 of the next instruction's first row: both write the same bytes)
     const uint32_t dmaoff = (uint32_t)(lane / 9) * row_bytes + (uint32_t)(lane % 9) * 16u;
-    const uint32_t ldsd = ring + 2 * X64_STAGE + (uint32_t)h * 64u;
+    const uint32_t ldsd = ring + 2 * (one_tile ? X64_STAGE_R1 : X64_STAGE) + (uint32_t)h * 64u;
     const uint32_t nsb = (uint32_t)(sb_end - sb_begin);
+    X64_STAMP(1);
     if constexpr (T == GGQ_TYPE_Q8_0) {   // 272 bytes of a row per 256 elements, in two 128-element stages at a 144-byte LDS pitch
       const uint32_t hoff = 16u * (uint32_t)h;
       x64_loop_q80(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                    sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else {
       const uint32_t hoff = 16u + 16u * (uint32_t)h;
-      x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                   sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+      if (one_tile)
+        x64_loop_q4k_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+      else
+        x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                     sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     }
   }
 
-  // ---- K-slice reduction: red[slice][tile][register][lane]; the rings are dead once every wave is past its last ds_read ----
+  X64_STAMP(2);
+  // ---- K-slice reduction: red[slice][tile][register][lane] (R3: the one-tile waves' red1[slice][token tile][register][lane] behind it);
+  // the rings are dead once every wave is past its last ds_read ----
   __syncthreads();
+  X64_STAMP(3);
   float* red = (float*)lds;
+  float* red1 = red + KS * 4096;
+  if (!one_tile) {
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    red[((ks * 4 + (i >> 4)) * 16 + (i & 15)) * 64 + lane] = acc0[i];
-    red[((ks * 4 + 2 + (i >> 4)) * 16 + (i & 15)) * 64 + lane] = acc1[i];
+    for (int i = 0; i < 32; ++i) {
+      red[((ks * 4 + (i >> 4)) * 16 + (i & 15)) * 64 + lane] = acc0[i];
+      red[((ks * 4 + 2 + (i >> 4)) * 16 + (i & 15)) * 64 + lane] = acc1[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      red1[((ks * 2 + 0) * 16 + i) * 64 + lane] = acc0[i];
+      red1[((ks * 2 + 1) * 16 + i) * 64 + lane] = acc1[i];
+    }
   }
   __syncthreads();
-  // thread -> (token tl64 of the unit, 16 consecutive rows): lane (row r, half h) of tile (rt, tt) holds token 32 tt + 8 (i >> 2) + 4 h + (i & 3)
+  X64_STAMP(4);
+  // thread -> (token tl64 of the unit, RPT consecutive rows): lane (row r, half h) of tile (rt, tt) holds token 32 tt + 8 (i >> 2) + 4 h + (i & 3)
   // of row 32 rt + r in register i, so four consecutive rows of one token are four consecutive floats of red[]
-  constexpr int RPT = 4096 / (64 * KS);   // rows per thread: 16 (four waves) or 8 (eight)
-  const int tl64 = tid / (64 / RPT), rb = (tid % (64 / RPT)) * RPT;
+  constexpr int NTHR = R3 ? 512 : 64 * KS;
+  constexpr int RPT = UROWS * 64 / NTHR;   // rows per thread: 16 (four waves), 8 (eight), 12 (96-row units)
+  const int tl64 = tid / (UROWS / RPT), rb = (tid % (UROWS / RPT)) * RPT;
   const int t = t0 + tl64;
   if (t >= batch) return;
   const int tt = tl64 >> 5, tl = tl64 & 31;
@@ -124,11 +186,18 @@ __global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __re
 #pragma unroll
   for (int j = 0; j < RPT / 4; ++j) {
     const int R = rb + 4 * j, rt = R >> 5, rr = R & 31;
-    v4f s = *(const v4f*)(red + (((0 * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
+    v4f s;
+    if (R3 && rt == 2) {
+      s = *(const v4f*)(red1 + (((0 * 2 + tt) * 16 + i_reg) * 64 + 32 * hh + rr));
 #pragma unroll
-    for (int sl = 1; sl < KS; ++sl) {
-      const v4f p = *(const v4f*)(red + (((sl * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
-      s += p;   // fixed slice order ((0 + 1) + 2) + 3 ...
+      for (int sl = 1; sl < KS; ++sl) s += *(const v4f*)(red1 + (((sl * 2 + tt) * 16 + i_reg) * 64 + 32 * hh + rr));
+    } else {
+      s = *(const v4f*)(red + (((0 * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
+#pragma unroll
+      for (int sl = 1; sl < KS; ++sl) {
+        const v4f p = *(const v4f*)(red + (((sl * 4 + 2 * tt + rt) * 16 + i_reg) * 64 + 32 * hh + rr));
+        s += p;   // fixed slice order ((0 + 1) + 2) + 3 ...
+      }
     }
     v[4 * j] = s[0]; v[4 * j + 1] = s[1]; v[4 * j + 2] = s[2]; v[4 * j + 3] = s[3];
   }
@@ -139,6 +208,7 @@ __global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __re
     for (int e = 0; e < RPT; ++e)
       if (row0 + e < n_rows) v[e] = x64_apply_epilogue<DT>(v[e], epi, aux, yi0 + e, row0 + e);
   }
+  // 16-byte stores of eight fp16 / bf16 rows; the 12-row threads of the 96-row units (row0 a multiple of 12: 8-byte aligned) store 8 + 8 + 8 bytes
   const bool vec_ok = DT != GGQ_F32 && (ldy & 7) == 0 && ((uintptr_t)y & 15) == 0 && row0 + RPT <= n_rows;
   if (vec_ok) {
     uint32_t pk[RPT / 2];
@@ -154,35 +224,57 @@ __global__ void __launch_bounds__(64 * KS, 2) mmq_x64_kernel(const uint8_t* __re
       }
       pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
     }
-    v4i* dst = (v4i*)((uint16_t*)y + yi0);
-    dst[0] = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-    if constexpr (RPT == 16) dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
+    if constexpr (RPT == 12) {
+      v2i* dst = (v2i*)((uint16_t*)y + yi0);
+      dst[0] = v2i{(int)pk[0], (int)pk[1]};
+      dst[1] = v2i{(int)pk[2], (int)pk[3]};
+      dst[2] = v2i{(int)pk[4], (int)pk[5]};
+    } else {
+      v4i* dst = (v4i*)((uint16_t*)y + yi0);
+      dst[0] = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+      if constexpr (RPT == 16) dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < RPT; ++e)
       if (row0 + e < n_rows) Elem<DT>::st(y, yi0 + e, v[e]);
   }
+  X64_STAMP(5);
 }
 
 template <int T, int DT>
 static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
                       X64Epilogue ep) {
   const int64_t n_tok_tiles = (batch + 63) / 64;
-  const int64_t n_units = ((n + 63) / 64) * n_tok_tiles;
+  // -DGGQ_TUNING builds only (scripts/sweep_x64.py): GGQ_X64_KS forces 4 or 8 K-slices, GGQ_X64_ROWS 64- or 96-row units
+  static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");
+  static const char* er = GGQ_TUNING_ENV("GGQ_X64_ROWS");
+  const int unit_rows = T != GGQ_TYPE_Q4_K ? 64 : (er && (er[0] == '6' || er[0] == '9') ? (er[0] == '9' ? 96 : 64) : ggq_mmq_x64_unit_rows(T, batch, k, n));
+  const int64_t n_units = ((n + unit_rows - 1) / unit_rows) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
   const int64_t per_xcd = (n_units + 7) / 8;
   // at most one unit per CU: eight K-slices per unit (two waves per SIMD either way, half the K loop per wave); otherwise four, two
   // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable)
-  static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");   // -DGGQ_TUNING builds only (scripts/sweep_x64.py): force 4 or 8
   const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : ggq_mmq_x64_k_slices(batch, k, n);
+  if constexpr (T == GGQ_TYPE_Q4_K) {
+    if (unit_rows == 96) {
+      auto kern = mmq_x64_kernel<T, DT, 4, true>;
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64_LDS_R3) != hipSuccess) return GGQ_ERR_LAUNCH;
+      GGQ_HIP_PRE_LAUNCH();
+      hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64_LDS_R3, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
+                         (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+      GGQ_HIP_CHECK_LAUNCH();
+      return GGQ_OK;
+    }
+  }
   if (ks == 8 && k >= 8 * 256) {
-    auto kern = mmq_x64_kernel<T, DT, 8>;
+    auto kern = mmq_x64_kernel<T, DT, 8, false>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<8>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
     GGQ_HIP_PRE_LAUNCH();
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64Lds<8>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
                        (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
   } else {
-    auto kern = mmq_x64_kernel<T, DT, 4>;
+    auto kern = mmq_x64_kernel<T, DT, 4, false>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<4>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
     GGQ_HIP_PRE_LAUNCH();
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), X64Lds<4>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,

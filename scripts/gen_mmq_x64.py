@@ -59,6 +59,7 @@ X_NOD8 = int(os.environ.get("X64_NOD8", "0"))          # 1: no token-scale loads
 X_NOACT = int(os.environ.get("X64_NOACT", "0"))        # 1: no activation-fragment loads inside the loop (wrong results; timing experiments only)
 X_NOFILL = int(os.environ.get("X64_NOFILL", "0"))      # timing experiments only (wrong results): 1 no dw_prep, 2 no unpack + raw reads, 8 no header decode inside the loop
 X_NOWAIT = int(os.environ.get("X64_NOWAIT", "0"))      # timing experiments only (wrong results): 1 = no vmcnt waits inside the loop, 2 = no lgkmcnt waits, 3 = neither
+X_DMAEARLY = int(os.environ.get("X64_DMAEARLY", "0"))  # 1: the next stage's ten DMA instructions in groups 0 .. 2 (one per slot) instead of 0 .. 4
 X_NODMA = int(os.environ.get("X64_NODMA", "0"))        # 1: no LDS-DMA inside the loop, every super-block re-reads stage 0 (wrong results; determinism experiments only)
 
 
@@ -122,6 +123,14 @@ class Q4K:
     N_DMA = 10               # LDS-DMA instructions per stage: 7 rows (63 chunks) each, the last one row 63 alone
     QS_OFF = 16              # first quant byte inside the super-block
     STAGE = ROWS * 144
+    ROWS = ROWS
+
+
+class Q4K_R1(Q4K):
+    """one row tile per wave (32 rows x 64 tokens): the second wave kind of the 96-row units (mmq_x64.hip, R3)"""
+    ROWS = 32
+    N_DMA = 5                # 4 x 7 rows + 4
+    STAGE = 32 * 144
 
 
 class Q80:
@@ -134,17 +143,23 @@ class Q80:
     CPR, DIV = 9, 7282
     N_DMA = 10
     STAGE = ROWS * 144
+    ROWS = ROWS
 
 
 F = Q4K
+R1 = False                  # one-row-tile schedule (gen_r1): the tiles of a group are ti = 0, 2 and alternate the result sets
 RAW8 = (192, 200)           # Q8_0: two aligned 16-byte chunks of the row's stage per row tile (the Q4_K header / min-term registers are free)
 DREG = ((208, 209), (210, 211))   # Q8_0: the block's fp16 d, [row tile][group parity]
 S_RUNA, S_RUNB, S_NEXTW = 75, 76, 77   # Q8_0: running source offsets of the two stage copies, byte step to the next 256 elements
 
 
+def cset(g, ti):
+    return CSET[(2 * g + (ti >> 1)) & 1] if R1 else CSET[(4 * g + ti) & 1]
+
+
 def mfma(a, g, ti):
     rt, tt = ti & 1, ti >> 1
-    c = CSET[(4 * g + ti) & 1]
+    c = cset(g, ti)
     if ti == 0:
         a.wait_vm(f"act0_{g & 1}")
     if ti == 2:
@@ -160,7 +175,7 @@ def fma_block(a, g, ti):
     SIMD that instruction returned wrong low-half results in lanes 48-63 from time to time (profiles/r04_x64_nondeterminism.txt);
     with plain or packed fp32 FMAs the kernel is bit-reproducible."""
     rt, tt = ti & 1, ti >> 1
-    c = CSET[(4 * g + ti) & 1]
+    c = cset(g, ti)
     p = g & 1
     if ti in (0, 2):
         a.wait_lg(f"d8_{tt}")
@@ -260,7 +275,12 @@ def dma_instr(a, j, dst_stage):
     a.i(f"s_add_u32 m0, {sr(dst_stage)}, {16 * 7 * F.CPR * j}")
     if j == F.N_DMA - 1:
         a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
-        a.i(f"s_mov_b64 exec, {hex((1 << (F.CPR * (ROWS - 7 * j))) - 1)}")
+        mask = (1 << (F.CPR * (F.ROWS - 7 * j))) - 1
+        if mask < (1 << 32):
+            a.i(f"s_mov_b64 exec, {hex(mask)}")
+        else:
+            a.i("s_mov_b32 exec_lo, -1")
+            a.i(f"s_mov_b32 exec_hi, {hex(mask >> 32)}")
     else:
         a.i("s_nop 0")                                                   # SALU write of M0 -> LDS-DMA: one wait state
     a.vmem(f"buffer_load_dwordx4 {vr(V_DMAOFF)}, {sr(S_WRSRC, 4)}, {sr(S_T1)} offen lds", "dma")
@@ -415,8 +435,11 @@ def gen(label):
                     raw_read(a, rt, q + 1)
                 else:
                     w_lo(a, rt)
-            if g <= 4 and ti < 2 and 2 * g + ti < F.N_DMA and not X_NODMA:
-                dma_instr(a, 2 * g + ti, S_NSTAGE)   # weight DMA of the next stage: nine instructions over groups 0 .. 4
+            if X_DMAEARLY:
+                if 4 * g + ti < F.N_DMA and not X_NODMA:
+                    dma_instr(a, 4 * g + ti, S_NSTAGE)   # weight DMA of the next stage: ten instructions over groups 0 .. 2
+            elif g <= 4 and ti < 2 and 2 * g + ti < F.N_DMA and not X_NODMA:
+                dma_instr(a, 2 * g + ti, S_NSTAGE)   # weight DMA of the next stage: ten instructions over groups 0 .. 4
             if g == 0 and ti >= 2:
                 d8_dma(a, ti - 2, 1, False)      # token scales of groups 4-7 of this super-block
             if (g, ti) == (3, 2):
@@ -494,6 +517,150 @@ def gen(label):
         a.i("s_nop 3")
     a.i(f"s_branch L_warm_{label}%=")
     a.i(f"L_end_{label}%=:")
+    return a
+
+
+
+def gen_r1(label):
+    """Q4_K, ONE row tile per wave (32 rows x 64 tokens, tiles ti = 0, 2 = token tiles 0, 1; accumulators v[0:15], v[32:47]): the
+    second wave kind of the 96-row units.  Same pipeline as gen() with two slots per group: slot (g, 0) carries the loads (activations,
+    weight DMA), slot (g, 2) the unpack / scale work of the one row tile (its operand is free once MFMA(g, 2) has issued)."""
+    global F, R1
+    F, R1 = Q4K_R1, True
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    for s in (S_256, S_256 + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0x43800000")
+    a.i(f"s_mov_b32 {sr(S_MASK0F)}, 0x0f0f0f0f")
+    a.i(f"s_mov_b32 {sr(S_1024)}, 0x44800000")
+    a.i(f"v_cmp_ne_u32_e64 {sr(S_HI, 2)}, 16, {vr(V_HOFF)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_LDS)}")
+    a.i(f"s_add_u32 {sr(S_NSTAGE)}, {sr(S_LDS)}, {F.STAGE}")
+    a.i(f"s_mov_b32 {sr(S_WKN)}, {sr(S_WK)}")
+    for j in range(F.N_DMA):
+        dma_instr(a, j, S_STAGE)
+    s8_loads(a)
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    d8_dma(a, 0, 0, False)
+    d8_dma(a, 1, 0, False)
+    act_loads(a, 0)
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
+    d8_dma(a, 0, 1, False)                                        # groups 4-7 of the first super-block (later ones: in group 7 of the one before)
+    d8_dma(a, 1, 1, False)
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
+    a.i(f"v_add_u32 {vr(V_LDSWN)}, {F.STAGE}, {vr(V_LDSW0)}")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")
+    # the first "previous tile" FMA block, (7, 2): result set 1 = magic, zero token scales, zero row scales of the odd group -> adds zero
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[1] + k)}, 0")
+    for k in range(4, 8):
+        a.i(f"v_mov_b32 {vr(DWNM[0] + k)}, 0")
+    a.wait_vm("dma")
+    a.wait_vm("d8dma0_1")
+    hdr_read(a, 0)
+    a.lds(f"ds_read_b128 {vr(RAW[0], 4)}, {vr(V_LDSW)} offset:0", "raw0")
+    hdr_decode(a, 0)
+    w_lo(a, 0)
+    d8_reads(a, 0, 0)
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    a.i(f"L_sb_{label}%=:")
+    if a.vm[:2] == ["s8_0", "s8_1"]:
+        a.vm = a.vm[2:]
+    vm0, lg0 = list(a.vm), list(a.lg)
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
+    a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
+    for g in range(8):
+        q = g >> 1
+        # ------------------------------------------------ slot (g, 0)
+        mfma(a, g, 0)
+        act_loads(a, (g + 1) & 1)
+        advance_offsets(a, g)
+        for j in (2 * g, 2 * g + 1):
+            if j < F.N_DMA:
+                dma_instr(a, j, S_NSTAGE)        # the next stage: five instructions over groups 0 .. 2
+        if g == 1:
+            bmin_prep(a, 0)
+        if g == 3:
+            d8_dma(a, 0, 0, True)                # token tile 0's scales of groups 0-3 of the next super-block (this one's group 3 was read in slot (2, 2))
+        pg = (g - 1) % 8
+        fma_block(a, pg, 2)
+        d8_reads(a, 1, (pg + 1) % 8)
+        if pg == 2:
+            min_mfma(a, 2)
+        if g == 3:
+            a.i(f"v_cmp_nle_f32_e64 {sr(S_BIG, 2)}, |{vr(HDR[0] + 6)}|, {sr(S_1024)}")
+            a.i(f"s_cmp_lg_u64 {sr(S_BIG, 2)}, 0")
+            a.i(f"s_cbranch_scc1 L_cold_{label}%=")
+            a.i(f"L_warm_{label}%=:")
+            s8_loads(a)
+        # ------------------------------------------------ slot (g, 2)
+        mfma(a, g, 2)
+        if g == 6:
+            a.wait_vm("dma")
+        if g % 2 == 0:
+            w_hi(a, 0)
+            raw_read(a, 0, q + 1)
+            dw_prep(a, q, 0)                     # row scales of groups g, g + 1 (the odd group's old ones were last read in slot (g, 0))
+        else:
+            w_lo(a, 0)
+        if g == 3:
+            d8_dma(a, 1, 0, True)
+        if g == 6:
+            hdr_read(a, 0)
+        if g == 7:
+            hdr_decode(a, 0)
+            d8_dma(a, 0, 1, True)                # groups 4-7 of the next super-block (this one's group 7 was read in slots (6, 2) / (7, 0))
+            d8_dma(a, 1, 1, True)
+        fma_block(a, g, 0)
+        d8_reads(a, 0, (g + 1) % 8)
+        if g == 2:
+            min_mfma(a, 0)
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
+    a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_NSTAGE)}")
+    a.i(f"s_mov_b32 {sr(S_NSTAGE)}, {sr(S_T0)}")
+    a.i(f"v_mov_b32 {vr(T_DW)}, {vr(V_LDSW)}")
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSWN)}")
+    a.i(f"v_mov_b32 {vr(V_LDSWN)}, {vr(T_DW)}")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.wait_lg("d8_1")                            # token tile 1's group-7 scales (slot (7, 0)): the top of the body reads them without a wait of its own
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0, (a.vm, vm0, a.lg, lg0)
+    fma_block(a, 7, 2)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    a.i(f"s_branch L_end_{label}%=")
+    a.i(f"L_cold_{label}%=:")
+    bmin_prep(a, 0, scaled=True)
+    a.i("s_nop 7")                               # the operand's last register was written by the instruction before: without wait states the
+                                                 # first MFMA below read a stale one (token tile 0 of every one-tile row off by ~1 %); in gen()
+                                                 # row tile 1's preparation sits between row tile 0's and the first MFMA
+    z = CSET[1]                                  # free here: tile (2, 2)'s FMAs are done, MFMA(3, 2) comes after
+    for ti in (0, 2):
+        acc = ACC + 16 * ti
+        a.i(f"v_mfma_f32_32x32x16_f16 {vr(z, 16)}, {vr(S8[ti >> 1], 4)}, {vr(BMIN[0], 4)}, 0")
+        a.i("s_nop 7")
+        a.i("s_nop 7")
+        for j in range(0, 16, 2):
+            a.i(f"v_pk_fma_f32 {vr(acc + j, 2)}, {vr(z + j, 2)}, {sr(S_256, 2)}, {vr(acc + j, 2)}")
+        a.i("s_nop 3")
+    a.i(f"s_branch L_warm_{label}%=")
+    a.i(f"L_end_{label}%=:")
+    F, R1 = Q4K, False
     return a
 
 
@@ -671,9 +838,11 @@ static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v
 if __name__ == "__main__":
     a = gen("q4k")
     b = gen_q80("q80")
+    c = gen_r1("r1_q4k_")
     if "--list" in sys.argv:
-        print("\n".join((b if "q80" in sys.argv else a).lines))
+        print("\n".join((b if "q80" in sys.argv else c if "r1" in sys.argv else a).lines))
     with open(os.environ.get("X64_OUT", OUT), "w") as f:
         f.write(emit(a, "x64_loop_q4k"))
         f.write(emit(b, "x64_loop_q80"))
+        f.write(emit(c, "x64_loop_q4k_r1"))
     print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)

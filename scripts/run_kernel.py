@@ -10,7 +10,7 @@ t = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 K, N = int(os.environ.get('K', 4096)), int(os.environ.get('N', 11008))
-L = ggqlib.hip()
+L = ggqlib.hip() if not os.environ.get("GGQ_LIB") else ggqlib._bind(ctypes.CDLL(os.environ["GGQ_LIB"]), ggqlib.HIP_SYMBOLS)
 vp = lambda x: ctypes.c_void_p(x.data_ptr())
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 w = torch.from_numpy(synth.random_weight(t, N, K, seed=0)).cuda()

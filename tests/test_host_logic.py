@@ -143,6 +143,25 @@ def test_mmq_routing_table():
                 assert L.ggq_mmq_stream_unit_tokens(int(t), b, n) == want, (t, b, n)
 
 
+def test_x64_launch_shape_rules():
+    """K-slices and rows per unit of the 64 x 64 wave-tile kernel (ggq_mmq_x64_k_slices / ggq_mmq_x64_unit_rows): eight slices while a
+    unit has a CU to itself; 96-row units (Q4_K) exactly where 64-row units would need a second workgroup on some CUs and 96-row
+    units do not"""
+    from ggq import lib as ggqlib
+    L = ggqlib.cpu()
+    Q4_K, Q8_0 = 12, 8
+    assert L.ggq_mmq_x64_k_slices(128, 4096, 8192) == 8 and L.ggq_mmq_x64_k_slices(128, 4096, 8193) == 4
+    assert L.ggq_mmq_x64_k_slices(64, 1024, 4096) == 4                          # fewer than eight super-blocks
+    for b, k, n, want in ((128, 4096, 11008, 96), (128, 4096, 8192, 64), (128, 4096, 8193, 96), (128, 4096, 12288, 96), (128, 4096, 12289, 64),
+                          (64, 4096, 11008, 64), (256, 4096, 4100, 96), (256, 4096, 6145, 64), (2048, 1024, 600, 96), (128, 768, 11008, 64),
+                          (128, 4096, 28672, 64), (65, 1024, 8230, 96)):
+        assert L.ggq_mmq_x64_unit_rows(Q4_K, b, k, n) == want, (b, k, n)
+        assert L.ggq_mmq_x64_unit_rows(Q8_0, b, k, n) == 64
+        if want == 96:
+            tt = -(-b // 64)
+            assert -(-n // 64) * tt > 256 >= -(-n // 96) * tt
+
+
 def test_shipped_code_objects_keep_the_mfma_wait_states():
     """scripts/audit_kernels.py over lib/libggq_hip.so: every v_mfma_i32_32x32x32_i8 keeps the wait states the hardware was
     measured to need and not to interlock (scripts/ubench_mfma_hazard.hip, profiles/r03_ubench_mfma_hazard.txt)"""

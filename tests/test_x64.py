@@ -51,6 +51,42 @@ def test_mmq_x64_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 mmq {t.name} b={batch}")
 
 
+@pytest.mark.parametrize("dtype,batch,k,n_rows", [(torch.float16, 128, 1024, 8230), (torch.float32, 100, 1280, 8257), (torch.bfloat16, 256, 1024, 4100),
+                                                  (torch.float16, 2048, 1024, 600), (torch.float16, 128, 4096, 8200)])
+def test_mmq_x64_96_row_units(oracle, dtype, batch, k, n_rows):
+    """launches that take the 96-row units (four two-row-tile waves + four one-row-tile waves per workgroup; Q4_K): against the oracle,
+    with a last unit of 6 / 1 / 68 / 24 / 40 rows (the one-row-tile waves partly or not at all in the tensor); and a row's bits do not
+    depend on the unit shape — the first rows equal the 64-row-unit launch of those rows alone"""
+    t = GGMLType.Q4_K
+    L = ggqlib.hip()
+    assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, n_rows) == 96
+    w = synth.random_weight(t, n_rows, k, seed=batch + k)
+    # every seventh row: dmin over the whole range, incl. the 2^-8-scaled cold pass of both wave kinds (test_mmq_x64_min_scale_range)
+    from ggq.synth import _F16_FIELDS
+    bs, m_off = BLOCK[t][1], _F16_FIELDS[t][1]
+    wb = w.reshape(n_rows, -1, bs)
+    vals = np.array([6e-8, 1.0, 1023.5, 1024.5, 65504.0, -65504.0, -3.0, 0.0, -2000.0], np.float16)
+    for r in range(0, n_rows if dtype != torch.float16 else 0, 7):   # (fp16 outputs would overflow)
+        for b in range(wb.shape[1]):
+            wb[r, b, m_off:m_off + 2] = vals[(r + 5 * b) % len(vals)].reshape(1).view(np.uint8)
+    w = wb.reshape(n_rows, -1)
+    x = _x((batch, k), dtype, seed=17)
+    y = util.gpu_mmq_x64(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 96-row units b={batch}")
+    if k < 2048:   # (four K-slices whatever the unit count)
+        sub = 200
+        assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, sub) == 64
+        ys = util.gpu_mmq_x64(np.ascontiguousarray(w[:sub]), x, t, sub)
+        assert torch.equal(ys, y[:, :sub].contiguous()), "a row's result depends on the unit shape"
+    else:          # a taller matrix with the same rows first: 64-row units, four K-slices (more than 256 units)
+        big = 12352
+        assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, big) == 64 and L.ggq_mmq_x64_k_slices(batch, k, big) == 4
+        yb = util.gpu_mmq_x64(np.concatenate([w, w[: big - n_rows]]), x, t, big)
+        assert torch.equal(yb[:, :n_rows].contiguous(), y), "a row's result depends on the unit shape"
+    assert torch.equal(y, util.gpu_mmq_x64(w, x, t, n_rows)), "two launches differ"
+
+
 @pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
 def test_mmq_x64_integer_exact(oracle, t):
     """power-of-two scales + integer activations: every product and partial sum is exact, so the result must equal the oracle's to
