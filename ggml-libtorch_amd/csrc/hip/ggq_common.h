@@ -194,6 +194,20 @@ struct GatherOut {
   int n_dst, n_flag;
 };
 
+// one element into every peer slot (the scalar tail of a multi-destination write-back; system-scope relaxed stores)
+template <int DT>
+__device__ __forceinline__ void gather_store(const GatherOut& go, int64_t idx, float v) {
+  for (int d = 1; d < go.n_dst; ++d) {   // (kernel-uniform trip count; 0 iterations in a plain launch)
+    if constexpr (DT == GGQ_F32) {
+      __hip_atomic_store((uint32_t*)go.dst[d] + idx, __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      uint16_t bits;
+      Elem<DT>::st(&bits, 0, v);
+      __hip_atomic_store((uint16_t*)go.dst[d] + idx, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // Experiment knobs (environment variables that force a kernel variant) exist only in -DGGQ_TUNING builds
 // (scripts/build_variant.sh); the shipped library takes no decision from the environment.
 #ifdef GGQ_TUNING

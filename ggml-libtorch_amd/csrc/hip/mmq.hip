@@ -608,7 +608,7 @@ namespace ggq {
 //   GGQ_EPI_BIAS      y = acc + bias[row]                          aux: bias, n_rows elements of the output dtype
 //   GGQ_EPI_SILU_MUL  y = silu(gate[token, row]) * acc             aux: gate, same [batch, ldy] layout as y
 // applied to the fp32 accumulator before the one rounding to the output dtype.
-struct Epilogue { int kind = GGQ_EPI_NONE; const void* aux = nullptr; };
+struct Epilogue { int kind = GGQ_EPI_NONE; const void* aux = nullptr; GatherOut go = GatherOut{}; };
 template <int DT>
 __device__ __forceinline__ float apply_epilogue(float v, int epi, const void* aux, int64_t yi, int row) {
   if (epi == GGQ_EPI_BIAS) return v + Elem<DT>::ld(aux, row);
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
                                                             const uint8_t* __restrict__ q8,
                                                             void* __restrict__ y, int k, int n_rows, int batch,
                                                             int64_t ldy, int n_tok_tiles, int n_units, int per_xcd,
-                                                            int epi, const void* __restrict__ aux) {
+                                                            int epi, const void* __restrict__ aux, GatherOut go) {
   using C = StreamCfg<T>;
   using TR = MmqTraits<T>;
   constexpr int SEG = C::SEG, STAGE = C::STAGE, IPS = C::IPS;
@@ -1272,10 +1272,30 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
       pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
       *(uint2*)((uint16_t*)y + (int64_t)t * ldy + row) = pk;
+      for (int d = 1; d < go.n_dst; ++d) {   // (kernel-uniform) the peers' slots: system-coherent write-through stores
+        uint16_t* p = (uint16_t*)go.dst[d] + (int64_t)t * ldy + row;
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(pk) : "memory");
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (row + e < n_rows) Elem<DT>::st(y, (int64_t)t * ldy + row + e, v[e]);
+        if (row + e < n_rows) {
+          Elem<DT>::st(y, (int64_t)t * ldy + row + e, v[e]);
+          gather_store<DT>(go, (int64_t)t * ldy + row + e, v[e]);
+        }
+    }
+  };
+  // publish (multi-destination launches): a wave that has stored drains its own stores (write-through: complete at vmcnt 0) and
+  // arrives; the last of the launch's `n_units * waves_that_store` arrivals writes the flags — the one release at system scope
+  auto gather_arrive = [&](int storing_waves) {
+    if (go.n_flag <= 0) return;   // (kernel-uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const uint32_t before = __hip_atomic_fetch_add(go.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (uint32_t)n_units * (uint32_t)storing_waves - 1u) {
+        __hip_atomic_store(go.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int d = 0; d < go.n_flag; ++d) __hip_atomic_store(go.flag[d], go.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   };
 
@@ -1315,6 +1335,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
     GGQ_STAMP(3);
     switch (ks) { case 0: finish(Q0{}); break; case 1: finish(Q1{}); break; case 2: finish(Q2{}); break; default: finish(Q3{}); }
     GGQ_STAMP(4);
+    gather_arrive(4);
     return;
   }
 
@@ -1342,7 +1363,11 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 #pragma unroll
       for (int i = 0; i < NLIVE; ++i) {
         const int t = t0 + 32 * jj + 8 * (i >> 2) + 4 * h + (i & 3);
-        if (t < batch) Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, apply_epilogue<DT>(acc[jj][i], epi, aux, (int64_t)t * ldy + n0 + r, n0 + r));
+        if (t < batch) {
+          const float o = apply_epilogue<DT>(acc[jj][i], epi, aux, (int64_t)t * ldy + n0 + r, n0 + r);
+          Elem<DT>::st(y, (int64_t)t * ldy + n0 + r, o);
+          gather_store<DT>(go, (int64_t)t * ldy + n0 + r, o);
+        }
       }
     }
   } else {
@@ -1355,6 +1380,7 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
       }
   }
   GGQ_STAMP(4);
+  gather_arrive(1);
 }
 
 template <int T, int DT, int TB, int KS, int NR>
@@ -1370,7 +1396,7 @@ static int launch_mmq_stream_ks(const void* w, const void* q8, void* y, int64_t 
   GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(64 * KS), LDS, s,
                      (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n, (int)batch, ldy,
-                     (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+                     (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }
@@ -1423,6 +1449,11 @@ static int launch_mmq_tiled(const void* w, const void* q8, void* y, int dt, int6
 }
 }  // namespace ggq
 
+namespace ggq {
+int mul_mat_q_stream_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
+                          int64_t ldy, int epilogue, const void* aux, void* stream, const void* go);
+}
+
 extern "C" int ggq_mmq_tiled_supported(int type, int64_t k) {
   // the streamed kernel addresses a 32-row weight tile with 32-bit byte offsets: rows up to 32 MiB (K of a few
   // tens of millions); longer rows stay on the reference-layout kernel
@@ -1438,9 +1469,15 @@ extern "C" int ggq_mul_mat_q_pretiled(const void* w, const void* q, void* y, int
 extern "C" int ggq_mul_mat_q_pretiled_epi(const void* w, const void* q, void* y, int type, int dtype,
                                           int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                                           int epilogue, const void* aux, void* stream) {
+  return ggq::mul_mat_q_stream_impl(w, q, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream, nullptr);
+}
+
+// the streamed kernel behind ggq_mul_mat_q_pretiled_epi; go != nullptr: with the multi-destination write-back (ggq_mul_mat_q_gather)
+int ggq::mul_mat_q_stream_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
+                               int64_t ldy, int epilogue, const void* aux, void* stream, const void* go) {
   using namespace ggq;
   if (epilogue < GGQ_EPI_NONE || epilogue > GGQ_EPI_SILU_MUL || (epilogue != GGQ_EPI_NONE && !aux)) return GGQ_ERR_ARG;
-  const Epilogue ep{epilogue, aux};
+  const Epilogue ep{epilogue, aux, go ? *(const GatherOut*)go : GatherOut{}};
   if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
   if (!ggq_mmq_type_supported(type)) return GGQ_ERR_TYPE;
   if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;

@@ -474,7 +474,7 @@ template <int T, int DT, int ROWS, bool FUSED, bool KSPLIT>
 __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t* __restrict__ w,
                                                    const uint8_t* __restrict__ q8,
                                                    void* __restrict__ y, int k, int n_rows,
-                                                   int rows_per_wave) {
+                                                   int rows_per_wave, GatherOut go) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   int8_t* xq = (int8_t*)lds;
   float* xd = (float*)(lds + k);
@@ -654,7 +654,10 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
 #pragma unroll
         for (int r = 1; r < ROWS; ++r) tot += acc[r];
         tot = wave_sum(tot);
-        if (lane == 0) Elem<DT>::st(y, r0, tot);
+        if (lane == 0) {
+          Elem<DT>::st(y, r0, tot);
+          gather_store<DT>(go, r0, tot);
+        }
         continue;
       }
     }
@@ -673,14 +676,28 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const float tot = wave_sum(acc[r]);
-      if (lane == 0 && r0 + r < row_end) Elem<DT>::st(y, r0 + r, tot);
+      if (lane == 0 && r0 + r < row_end) {
+        Elem<DT>::st(y, r0 + r, tot);
+        gather_store<DT>(go, r0 + r, tot);
+      }
     }
   }
   VSTAMP(4);
+  if (go.n_flag > 0) {   // (kernel-uniform) multi-destination launch: every wave drains its own write-through stores and arrives;
+    // the last arrival of the launch writes the flags (the one release at system scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const uint32_t before = __hip_atomic_fetch_add(go.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == gridDim.x * (blockDim.x >> 6) - 1u) {
+        __hip_atomic_store(go.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int d = 0; d < go.n_flag; ++d) __hip_atomic_store(go.flag[d], go.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 template <int T, int DT, bool FUSED>
-static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int64_t n, hipStream_t s) {
+static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int64_t n, hipStream_t s, const GatherOut& go) {
   // rows in flight per wave: three in the fused kernel (a wave owns 2.7 rows at 11008 rows on 4096 waves: all of them go
   // out at once — Q4_0 10.7 -> 10.0 us cold, 7.9 -> 7.7 warm), two for Q8_0 (34-byte blocks: 15.3 vs 15.8 us cold)
   constexpr int ROWS = !FUSED ? 2 : (T == GGQ_TYPE_Q8_0 ? 2 : GGQ_MMVQ_ROWS);
@@ -705,43 +722,43 @@ static int launch_mmvq_t(const void* w, const void* q8, void* y, int64_t k, int6
   }
   GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FUSED ? 1024 : 256), lds, s, (const uint8_t*)w,
-                     (const uint8_t*)q8, y, (int)k, (int)n, rpw);
+                     (const uint8_t*)q8, y, (int)k, (int)n, rpw, go);
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
 }
 
 template <int T>
-static int launch_mmvq(const void* w, const void* q8, void* y, int dt, int64_t k, int64_t n, bool fused, hipStream_t s) {
+static int launch_mmvq(const void* w, const void* q8, void* y, int dt, int64_t k, int64_t n, bool fused, hipStream_t s, const GatherOut& go) {
   switch (dt) {
-    case GGQ_F32: return fused ? launch_mmvq_t<T, GGQ_F32, true>(w, q8, y, k, n, s) : launch_mmvq_t<T, GGQ_F32, false>(w, q8, y, k, n, s);
-    case GGQ_F16: return fused ? launch_mmvq_t<T, GGQ_F16, true>(w, q8, y, k, n, s) : launch_mmvq_t<T, GGQ_F16, false>(w, q8, y, k, n, s);
-    case GGQ_BF16: return fused ? launch_mmvq_t<T, GGQ_BF16, true>(w, q8, y, k, n, s) : launch_mmvq_t<T, GGQ_BF16, false>(w, q8, y, k, n, s);
+    case GGQ_F32: return fused ? launch_mmvq_t<T, GGQ_F32, true>(w, q8, y, k, n, s, go) : launch_mmvq_t<T, GGQ_F32, false>(w, q8, y, k, n, s, go);
+    case GGQ_F16: return fused ? launch_mmvq_t<T, GGQ_F16, true>(w, q8, y, k, n, s, go) : launch_mmvq_t<T, GGQ_F16, false>(w, q8, y, k, n, s, go);
+    case GGQ_BF16: return fused ? launch_mmvq_t<T, GGQ_BF16, true>(w, q8, y, k, n, s, go) : launch_mmvq_t<T, GGQ_BF16, false>(w, q8, y, k, n, s, go);
     default: return GGQ_ERR_DTYPE;
   }
 }
 
 static int mmvq_dispatch(const void* w, const void* q, void* y, int type, int dtype, int64_t k, int64_t n_rows,
-                         bool fused, hipStream_t s) {
+                         bool fused, hipStream_t s, const GatherOut& go = GatherOut{}) {
   switch (type) {
-    case GGQ_TYPE_Q4_0: return launch_mmvq<GGQ_TYPE_Q4_0>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q4_1: return launch_mmvq<GGQ_TYPE_Q4_1>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q5_0: return launch_mmvq<GGQ_TYPE_Q5_0>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q5_1: return launch_mmvq<GGQ_TYPE_Q5_1>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q8_0: return launch_mmvq<GGQ_TYPE_Q8_0>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q2_K: return launch_mmvq<GGQ_TYPE_Q2_K>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q3_K: return launch_mmvq<GGQ_TYPE_Q3_K>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q4_K: return launch_mmvq<GGQ_TYPE_Q4_K>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q5_K: return launch_mmvq<GGQ_TYPE_Q5_K>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ4_NL: return launch_mmvq<GGQ_TYPE_IQ4_NL>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ4_XS: return launch_mmvq<GGQ_TYPE_IQ4_XS>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ2_XXS: return launch_mmvq<GGQ_TYPE_IQ2_XXS>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ2_XS: return launch_mmvq<GGQ_TYPE_IQ2_XS>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ2_S: return launch_mmvq<GGQ_TYPE_IQ2_S>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ3_XXS: return launch_mmvq<GGQ_TYPE_IQ3_XXS>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ3_S: return launch_mmvq<GGQ_TYPE_IQ3_S>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ1_S: return launch_mmvq<GGQ_TYPE_IQ1_S>(w, q, y, dtype, k, n_rows, fused, s);
-    case GGQ_TYPE_IQ1_M: return launch_mmvq<GGQ_TYPE_IQ1_M>(w, q, y, dtype, k, n_rows, fused, s);
+    case GGQ_TYPE_Q4_0: return launch_mmvq<GGQ_TYPE_Q4_0>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q4_1: return launch_mmvq<GGQ_TYPE_Q4_1>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q5_0: return launch_mmvq<GGQ_TYPE_Q5_0>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q5_1: return launch_mmvq<GGQ_TYPE_Q5_1>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q8_0: return launch_mmvq<GGQ_TYPE_Q8_0>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q2_K: return launch_mmvq<GGQ_TYPE_Q2_K>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q3_K: return launch_mmvq<GGQ_TYPE_Q3_K>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q4_K: return launch_mmvq<GGQ_TYPE_Q4_K>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q5_K: return launch_mmvq<GGQ_TYPE_Q5_K>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_Q6_K: return launch_mmvq<GGQ_TYPE_Q6_K>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ4_NL: return launch_mmvq<GGQ_TYPE_IQ4_NL>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ4_XS: return launch_mmvq<GGQ_TYPE_IQ4_XS>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ2_XXS: return launch_mmvq<GGQ_TYPE_IQ2_XXS>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ2_XS: return launch_mmvq<GGQ_TYPE_IQ2_XS>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ2_S: return launch_mmvq<GGQ_TYPE_IQ2_S>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ3_XXS: return launch_mmvq<GGQ_TYPE_IQ3_XXS>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ3_S: return launch_mmvq<GGQ_TYPE_IQ3_S>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ1_S: return launch_mmvq<GGQ_TYPE_IQ1_S>(w, q, y, dtype, k, n_rows, fused, s, go);
+    case GGQ_TYPE_IQ1_M: return launch_mmvq<GGQ_TYPE_IQ1_M>(w, q, y, dtype, k, n_rows, fused, s, go);
     default: return GGQ_ERR_TYPE;
   }
 }
@@ -781,4 +798,37 @@ extern "C" int ggq_mul_mat_vec_q(const void* w, const void* x, void* y, int type
     return ggq_mul_mat_vec_q_prequant(w, scratch, y, type, dtype, k, n_rows, stream);
   }
   return mmvq_dispatch(w, x, y, type, dtype, k, n_rows, true, (hipStream_t)stream);
+}
+
+// The fused GEMV with the multi-destination write-back (the batch-1 side of ggq_mul_mat_q_gather): Y (n_rows elements) goes to
+// dsts[0 .. n_dst), and once every wave of the launch has drained its stores `generation` is written into flags[0 .. n_flag).
+extern "C" int ggq_mul_mat_vec_q_gather(const void* w, const void* x, void* const* dsts, int n_dst, void* const* flags, int n_flag,
+                                        uint32_t generation, void* arrivals, int type, int dtype, int64_t k, int64_t n_rows,
+                                        void* stream) {
+  using namespace ggq;
+  if (n_dst < 1 || n_dst > 8 || n_flag < 0 || n_flag > 8 || !dsts || (n_flag && (!flags || !arrivals))) return GGQ_ERR_ARG;
+  if (k <= 0 || n_rows < 0) return GGQ_ERR_ARG;
+  if (!ggq_type_supported(type)) return GGQ_ERR_TYPE;
+  if (k % ggq_block_elems(type)) return GGQ_ERR_SHAPE;
+  if (k > 0x7fffffffLL / 64 || n_rows > 0x7fffffffLL) return GGQ_ERR_SHAPE;
+  if (dtype < GGQ_F32 || dtype > GGQ_BF16) return GGQ_ERR_DTYPE;
+  if (n_rows == 0) return GGQ_ERR_SHAPE;   // nothing would publish the flags
+  if (!w || !x) return GGQ_ERR_ARG;
+  if ((uintptr_t)w & 1) return GGQ_ERR_ALIGN;
+  GatherOut go{};
+  const uintptr_t emask = dtype == GGQ_F32 ? 3 : 1;
+  for (int d = 0; d < n_dst; ++d) {
+    if (!dsts[d]) return GGQ_ERR_ARG;
+    if ((uintptr_t)dsts[d] & emask) return GGQ_ERR_ALIGN;
+    go.dst[d] = dsts[d];
+  }
+  for (int d = 0; d < n_flag; ++d) {
+    if (!flags[d] || ((uintptr_t)flags[d] & 3)) return GGQ_ERR_ARG;
+    go.flag[d] = (uint32_t*)flags[d];
+  }
+  go.arrivals = (uint32_t*)arrivals;
+  go.generation = generation;
+  go.n_dst = n_dst;
+  go.n_flag = n_flag;
+  return mmvq_dispatch(w, x, dsts[0], type, dtype, k, n_rows, true, (hipStream_t)stream, go);
 }

@@ -207,8 +207,9 @@ class PeerSlabGather:
 
     def matmul_gather(self, x: torch.Tensor, w: torch.Tensor, quant_type, scratch: torch.Tensor = None):
         """y_rank = x · w_rankᵀ written by the GEMM kernel ITSELF into slot `rank` of every rank's buffer, flags published by the
-        kernel's last workgroup (ggq_mul_mat_q_gather: no copy, no second launch), then the wait for the peers' flags.  Falls back to
-        ggq_mul_mat_q_ld into `local` + gather() for the (format, batch, shape) the 16-token-tile kernel does not serve.
+        kernel's last arrival (ggq_mul_mat_q_gather — the 16-token-tile and the streamed kernel; one token: ggq_mul_mat_vec_q_gather,
+        the fused GEMV: no copy, no second launch), then the wait for the peers' flags.  Falls back to ggq_mul_mat_q_ld into `local` +
+        gather() for the (format, batch, shape) the other kernels serve (dot4 / LDS-tile / 64 x 64 wave tiles).
         w: this rank's [rows, row_bytes] shard on the device; x: [batch, k]."""
         import ctypes
         from . import lib as ggqlib
@@ -237,9 +238,13 @@ class PeerSlabGather:
         flag_word = self._flags_off + (par * 64 + self.rank) * 4
         dsts = (ctypes.c_void_p * (len(peers) + 1))(self._mem.data_ptr() + slot, *[self._peer_ptr[p] + slot for p in peers])
         flg = (ctypes.c_void_p * (len(peers) + 1))(self._mem.data_ptr() + flag_word, *[self._peer_ptr[p] + flag_word for p in peers])
-        rc = L.ggq_mul_mat_q_gather(vp(w), vp(x), dsts, len(peers) + 1, flg, len(peers) + 1, gen, ctypes.c_void_p(self._arrivals), t,
-                                    ggqlib.dtype_code(x.dtype), self.batch, k, self.rows, self.rows, vp(scratch), stream)
-        if rc == -2:   # GGQ_ERR_SHAPE: not a 16-token-tile shape
+        if self.batch == 1:   # the reference's dispatch: one token goes to the GEMV (HK/ggml/ggml_kernel.cu:145-189)
+            rc = L.ggq_mul_mat_vec_q_gather(vp(w), vp(x), dsts, len(peers) + 1, flg, len(peers) + 1, gen, ctypes.c_void_p(self._arrivals), t,
+                                            ggqlib.dtype_code(x.dtype), k, self.rows, stream)
+        else:
+            rc = L.ggq_mul_mat_q_gather(vp(w), vp(x), dsts, len(peers) + 1, flg, len(peers) + 1, gen, ctypes.c_void_p(self._arrivals), t,
+                                        ggqlib.dtype_code(x.dtype), self.batch, k, self.rows, self.rows, vp(scratch), stream)
+        if rc == -2 and self.batch > 1:   # GGQ_ERR_SHAPE: a route without its own multi-destination write-back
             ggqlib.check(L.ggq_mul_mat_q_ld(vp(w), vp(x), vp(self.local), t, ggqlib.dtype_code(x.dtype), self.batch, k, self.rows, self.rows,
                                            vp(scratch), stream), "ggq_mul_mat_q_ld")
             return self.gather()

@@ -57,6 +57,7 @@ HIP_SYMBOLS = {
     "ggq_peer_scatter": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, c_int64, c_int64, c_int64,
                                  ctypes.c_uint32, c_void_p, c_void_p]),
     "ggq_peer_wait": (c_int, [c_void_p, c_int, ctypes.c_uint32, c_void_p, c_void_p]),
+    "ggq_mul_mat_vec_q_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_uint32, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
     "ggq_mul_mat_q_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_uint32, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
 }
 CPU_SYMBOLS = {

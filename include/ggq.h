@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 8   /* 8: ggq_*_x64 (64 x 64 wave tiles, batches from 33 tokens), GGQ_MMQ_ROUTE_X64; 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather; 7: ggq_mmq_stream_unit_tokens */
+#define GGQ_ABI_VERSION 9   /* 9: ggq_mmq_x64_unit_rows, ggq_mul_mat_vec_q_gather, ggq_mul_mat_q_gather on the streamed route; 8: ggq_*_x64 (64 x 64 wave tiles, batches from 33 tokens), GGQ_MMQ_ROUTE_X64; 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather; 7: ggq_mmq_stream_unit_tokens */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -295,11 +295,16 @@ int ggq_peer_wait(const void* flags, int n_src, uint32_t generation, void* statu
  * stored into dsts[0 .. n_dst) — dsts[0] the caller's own slot, the others the same slot of the peers' gather buffers — and once
  * every workgroup has released its stores at system scope `generation` is written into flags[0 .. n_flag) (ggq_peer_wait on the
  * consumer side, as after ggq_peer_scatter; `arrivals` as there).  dsts / flags: HOST arrays of device pointers, at most 8 each.
- * Only for the (type, batch, shape) ggq_mmq_route() sends to the 16-token-tile kernel (GGQ_MMQ_ROUTE_T16); GGQ_ERR_SHAPE
- * otherwise — the caller then falls back to ggq_mul_mat_q_ld into its own slot + ggq_peer_scatter. */
+ * For the (type, batch, shape) ggq_mmq_route() sends to the 16-token-tile kernel (GGQ_MMQ_ROUTE_T16: the last workgroup publishes) or
+ * to the streamed kernel (GGQ_MMQ_ROUTE_STREAM: every wave that stores arrives, the last arrival publishes); GGQ_ERR_SHAPE
+ * otherwise — the caller then falls back to ggq_mul_mat_q_ld into its own slot + ggq_peer_scatter.
+ * ggq_mul_mat_vec_q_gather: the same for one token — the fused GEMV (ggq_mul_mat_vec_q) storing its n_rows outputs into
+ * dsts[0 .. n_dst) and publishing from its last wave; every format of ggq_mul_mat_vec_q. */
 int ggq_mul_mat_q_gather(const void* w, const void* x, void* const* dsts, int n_dst, void* const* flags, int n_flag,
                          uint32_t generation, void* arrivals, int type, int dtype, int64_t batch, int64_t k,
                          int64_t n_rows, int64_t ldy, void* scratch, void* stream);
+int ggq_mul_mat_vec_q_gather(const void* w, const void* x, void* const* dsts, int n_dst, void* const* flags, int n_flag,
+                             uint32_t generation, void* arrivals, int type, int dtype, int64_t k, int64_t n_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -567,6 +567,7 @@ def gen_r1(label):
     w_lo(a, 0)
     d8_reads(a, 0, 0)
     a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    Asm.armed = True
     a.i(f"L_sb_{label}%=:")
     if a.vm[:2] == ["s8_0", "s8_1"]:
         a.vm = a.vm[2:]
@@ -639,6 +640,7 @@ def gen_r1(label):
     a.wait_lg("d8_1")                            # token tile 1's group-7 scales (slot (7, 0)): the top of the body reads them without a wait of its own
     a.i(f"s_cbranch_scc1 L_sb_{label}%=")
     assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0, (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
     fma_block(a, 7, 2)
     a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.i("s_nop 7")

@@ -39,22 +39,36 @@ def main():
         for x, got in consumed:
             full = util.gpu_mmq(w, x, t, n_rows)    # the one-GPU result: every slab is computed by the same kernels
             ok = ok and torch.equal(got, full.float() * 2.0)
-    # the GEMM's own multi-destination write-back (ggq_mul_mat_q_gather): batch 8 goes through the 16-token-tile kernel, whose last
-    # workgroup publishes the flags; batch 40 takes the fallback (ggq_mul_mat_q_ld + scatter) inside the same call
-    for b2 in (8, 40):
-        with PeerSlabGather(b2, n_rows, torch.float16, torch.device("cuda", 0)) as pg:
-            wd = torch.from_numpy(w[s:e]).cuda()
+    # the kernels' own multi-destination write-back: batch 8 goes through the 16-token-tile kernel (its last workgroup publishes the
+    # flags), batch 40 and 128 (BASELINE config 5's batch) through the streamed kernel (every wave that stores arrives; 32- and
+    # 64-token units, four K-slices), batch 1 through the fused GEMV (ggq_mul_mat_vec_q_gather); Q2_K at batch 2 is a dot4 shape:
+    # the fallback (ggq_mul_mat_q_ld + scatter) inside the same call.  A taller matrix for batch 128 (several units per rank,
+    # a ragged last row tile), fp32 / bf16 outputs once each (scalar peer stores).
+    from ggq import lib as ggqlib
+    L = ggqlib.hip()
+    cases = [(t, 8, n_rows, torch.float16, 4), (t, 40, n_rows, torch.float16, 3), (t, 128, 200 * world, torch.float16, 3),
+             (t, 1, n_rows, torch.float16, None), (t, 1, 1376 * world, torch.float16, None), (GGMLType.Q8_0, 128, 72 * world, torch.float32, 3),
+             (GGMLType.Q6_K, 48, 40 * world, torch.bfloat16, 3), (GGMLType.Q2_K, 2, n_rows, torch.float16, 1)]
+    for (t2, b2, n2, dt2, want_route) in cases:
+        w2 = synth.random_weight(t2, n2, k, seed=21 + b2)
+        s2, e2 = shard_rows(n2, world, rank)
+        if want_route is not None:
+            assert L.ggq_mmq_route(int(t2), b2, k, e2 - s2) == want_route, (t2, b2, e2 - s2, L.ggq_mmq_route(int(t2), b2, k, e2 - s2))
+        with PeerSlabGather(b2, n2, dt2, torch.device("cuda", 0)) as pg:
+            wd = torch.from_numpy(w2[s2:e2]).cuda()
             seen = []
             for it in range(5):
-                x = torch.randn((b2, k), generator=torch.Generator().manual_seed(40 + it)).half().cuda()
+                x = torch.randn((b2, k), generator=torch.Generator().manual_seed(40 + it)).to(dt2).cuda()
                 if rank == it % world:
                     torch.cuda._sleep(10_000_000)
-                pg.matmul_gather(x, wd, t)
+                pg.matmul_gather(x, wd, t2)
                 seen.append((x, pg.batch_major().float() + 1.0))
             torch.cuda.synchronize()
             assert pg.status() == 0, "a ggq_peer_wait timed out"
             for x, got in seen:
-                ok = ok and torch.equal(got, util.gpu_mmq(w, x, t, n_rows).float() + 1.0)
+                # the one-GPU result of the same shards: every slab is computed by the kernel its rank's shape routes to
+                parts = [(util.gpu_mmvq if b2 == 1 else util.gpu_mmq)(w2[a:b], x, t2, b - a) for a, b in (shard_rows(n2, world, r) for r in range(world))]
+                ok = ok and torch.equal(got, torch.cat([p_.reshape(b2, -1) for p_ in parts], dim=1).float() + 1.0)
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
     dist.destroy_process_group()
