@@ -112,9 +112,9 @@ extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
 
 // rows of one unit: 96 (four two-row-tile waves + four one-row-tile waves, one workgroup per CU) where the launch then is ONE round of
 // at most 256 workgroups while 64-row units would put two workgroups on some CUs and one on the others (the two-workgroup CUs finish
-// 40-60 % later: profiles/r04_x64_stamps.txt); Q4_K only (the one-row-tile loop exists for it)
+// 40-60 % later: profiles/r04_x64_stamps.txt; the sweep behind the rule: profiles/r04_x64_unit_rows.txt)
 extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows) {
-  if (type != GGQ_TYPE_Q4_K || k < 4 * 256) return 64;
+  if (!ggq_mmq_x64_type_supported(type) || k < 4 * 256) return 64;
   const int64_t tt = (batch + 63) / 64;
   const int64_t u64 = ((n_rows + 63) / 64) * tt, u96 = ((n_rows + 95) / 96) * tt;
   return u64 > 256 && u96 <= 256 ? 96 : 64;

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
                                                          void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
                                                          int n_tok_tiles, int n_units, int per_xcd, int epi,
                                                          const void* __restrict__ aux) {
-  static_assert(!R3 || (KS == 4 && T == GGQ_TYPE_Q4_K), "96-row units: Q4_K, four K-slices");
+  static_assert(!R3 || KS == 4, "96-row units: four K-slices");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
   if (unit >= n_units) return;
@@ -138,6 +138,10 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
     X64_STAMP(1);
     if constexpr (T == GGQ_TYPE_Q8_0) {   // 272 bytes of a row per 256 elements, in two 128-element stages at a 144-byte LDS pitch
       const uint32_t hoff = 16u * (uint32_t)h;
+      if (one_tile)
+        x64_loop_q80_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+      else
       x64_loop_q80(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                    sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else {
@@ -249,14 +253,14 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
   // -DGGQ_TUNING builds only (scripts/sweep_x64.py): GGQ_X64_KS forces 4 or 8 K-slices, GGQ_X64_ROWS 64- or 96-row units
   static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");
   static const char* er = GGQ_TUNING_ENV("GGQ_X64_ROWS");
-  const int unit_rows = T != GGQ_TYPE_Q4_K ? 64 : (er && (er[0] == '6' || er[0] == '9') ? (er[0] == '9' ? 96 : 64) : ggq_mmq_x64_unit_rows(T, batch, k, n));
+  const int unit_rows = er && (er[0] == '6' || er[0] == '9') ? (er[0] == '9' ? 96 : 64) : ggq_mmq_x64_unit_rows(T, batch, k, n);
   const int64_t n_units = ((n + unit_rows - 1) / unit_rows) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
   const int64_t per_xcd = (n_units + 7) / 8;
   // at most one unit per CU: eight K-slices per unit (two waves per SIMD either way, half the K loop per wave); otherwise four, two
   // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable)
   const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : ggq_mmq_x64_k_slices(batch, k, n);
-  if constexpr (T == GGQ_TYPE_Q4_K) {
+  {
     if (unit_rows == 96) {
       auto kern = mmq_x64_kernel<T, DT, 4, true>;
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64_LDS_R3) != hipSuccess) return GGQ_ERR_LAUNCH;

@@ -210,7 +210,7 @@ int ggq_mmq_x64_type_supported(int type);
 int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch);
 /* K-slices (= waves) per 64 x 64 unit the x64 kernel uses for a shape: 8 while there is at most one unit per CU, else 4.  Host-only. */
 int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows);
-/* Weight rows per unit: 64, or 96 (Q4_K) where that makes the launch one even round of at most 256 workgroups.  Host-only. */
+/* Weight rows per unit: 64, or 96 where that makes the launch one even round of at most 256 workgroups.  Host-only. */
 int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows);
 int ggq_quantize_q8_1_x64(const void* x, int x_dtype, void* q, int64_t batch, int64_t k, int type, void* stream);
 int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,

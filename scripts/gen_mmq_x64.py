@@ -146,6 +146,12 @@ class Q80:
     ROWS = ROWS
 
 
+class Q80_R1(Q80):
+    ROWS = 32
+    N_DMA = 5
+    STAGE = 32 * 144
+
+
 F = Q4K
 R1 = False                  # one-row-tile schedule (gen_r1): the tiles of a group are ti = 0, 2 and alternate the result sets
 RAW8 = (192, 200)           # Q8_0: two aligned 16-byte chunks of the row's stage per row tile (the Q4_K header / min-term registers are free)
@@ -704,7 +710,12 @@ def q80_dma(a, j, buf, s_run, tag):
     a.i(f"s_add_u32 m0, {sr(S_LDS)}, {buf * F.STAGE + 16 * 7 * F.CPR * j}")
     if j == F.N_DMA - 1:
         a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
-        a.i(f"s_mov_b64 exec, {hex((1 << (F.CPR * (ROWS - 7 * j))) - 1)}")
+        mask = (1 << (F.CPR * (F.ROWS - 7 * j))) - 1
+        if mask < (1 << 32):
+            a.i(f"s_mov_b64 exec, {hex(mask)}")
+        else:
+            a.i("s_mov_b32 exec_lo, -1")
+            a.i(f"s_mov_b32 exec_hi, {hex(mask >> 32)}")
     else:
         a.i("s_nop 0")
     a.vmem(f"buffer_load_dwordx4 {vr(V_DMAOFF)}, {sr(S_WRSRC, 4)}, {sr(s_run)} offen lds", tag)
@@ -813,6 +824,104 @@ def gen_q80(label):
     return a
 
 
+def gen_q80_r1(label):
+    """Q8_0, one row tile per wave (32 rows x 64 tokens): gen_q80's pipeline with two slots per group, as gen_r1 is to gen.  Both stage
+    copies of the next 256 elements are issued inside the iteration (A in groups 2-3, B in groups 6-7: five instructions each)."""
+    global F, R1
+    F, R1 = Q80_R1, True
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
+    a.i(f"s_mov_b32 {sr(S_RUNA)}, {sr(S_WK)}")
+    for j in range(F.N_DMA):
+        q80_dma(a, j, 0, S_RUNA, "dmaA")
+    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    d8_dma(a, 0, 0, False)
+    d8_dma(a, 1, 0, False)
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[1] + k)}, 0")
+    for k in range(4, 8):
+        a.i(f"v_mov_b32 {vr(DWNM[0] + k)}, 0")
+    for j in range(3):                           # (issue order as at the end of the loop body)
+        q80_dma(a, j, 1, S_RUNB, "dmaB")
+    act_loads(a, 0)
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
+    for j in range(3, F.N_DMA):
+        q80_dma(a, j, 1, S_RUNB, "dmaB")
+    d8_dma(a, 0, 1, False)
+    d8_dma(a, 1, 1, False)
+    a.wait_vm("dmaA")
+    a.wait_vm("d8dma0_1")
+    q80_reads(a, 0, 0)
+    q80_w_prep(a, 0, 0)
+    q80_reads(a, 0, 1)
+    d8_reads(a, 0, 0)
+    Asm.armed = True
+    a.i(f"L_sb_{label}%=:")
+    vm0, lg0 = list(a.vm), list(a.lg)
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
+    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {2 * F.BS}")
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
+    for g in range(8):
+        # ------------------------------------------------ slot (g, 0)
+        mfma(a, g, 0)
+        q80_dw_prep(a, 0, g)
+        act_loads(a, (g + 1) & 1)
+        advance_offsets(a, g)
+        if g in (2, 3):                          # stage A of the next 256 elements (this iteration's last read of A: slot (1, 2))
+            for j in ((0, 1, 2) if g == 2 else (3, 4)):
+                if j == 0:
+                    a.i(f"s_add_u32 {sr(S_RUNA)}, {sr(S_WK)}, {sr(S_NEXTW)}")
+                q80_dma(a, j, 0, S_RUNA, "dmaA")
+        if g in (6, 7):                          # stage B of the next 256 elements (last read of B: slot (5, 2))
+            for j in ((0, 1, 2) if g == 6 else (3, 4)):
+                if j == 0:
+                    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_WK)}, {sr(S_NEXTW)}")
+                    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_RUNB)}, {F.BS}")
+                q80_dma(a, j, 1, S_RUNB, "dmaB")
+        if g == 3:
+            d8_dma(a, 0, 0, True)
+        pg = (g - 1) % 8
+        fma_block(a, pg, 2)
+        d8_reads(a, 1, (pg + 1) % 8)
+        # ------------------------------------------------ slot (g, 2)
+        mfma(a, g, 2)
+        if g == 2:
+            a.wait_vm("dmaB")                    # groups 4-7 of this iteration have landed: group 4's chunks are read below
+        if g == 6:
+            a.wait_vm("dmaA")                    # ... groups 0-3 of the next one
+        q80_w_prep(a, 0, g + 1)
+        q80_reads(a, 0, g + 2)
+        if g == 3:
+            d8_dma(a, 1, 0, True)
+        if g == 7:
+            d8_dma(a, 0, 1, True)
+            d8_dma(a, 1, 1, True)
+        fma_block(a, g, 0)
+        d8_reads(a, 0, (g + 1) % 8)
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {2 * F.BS}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.wait_lg("d8_1")
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
+    fma_block(a, 7, 2)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    F, R1 = Q4K, False
+    return a
+
+
 def emit(a, fn_name):
     asm = "\n".join(f'      "{l}\\n"' for l in a.lines)
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
@@ -841,10 +950,12 @@ if __name__ == "__main__":
     a = gen("q4k")
     b = gen_q80("q80")
     c = gen_r1("r1_q4k_")
+    d = gen_q80_r1("r1_q80_")
     if "--list" in sys.argv:
         print("\n".join((b if "q80" in sys.argv else c if "r1" in sys.argv else a).lines))
     with open(os.environ.get("X64_OUT", OUT), "w") as f:
         f.write(emit(a, "x64_loop_q4k"))
         f.write(emit(b, "x64_loop_q80"))
         f.write(emit(c, "x64_loop_q4k_r1"))
+        f.write(emit(d, "x64_loop_q80_r1"))
     print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)

@@ -156,7 +156,7 @@ def test_x64_launch_shape_rules():
                           (64, 4096, 11008, 64), (256, 4096, 4100, 96), (256, 4096, 6145, 64), (2048, 1024, 600, 96), (128, 768, 11008, 64),
                           (128, 4096, 28672, 64), (65, 1024, 8230, 96)):
         assert L.ggq_mmq_x64_unit_rows(Q4_K, b, k, n) == want, (b, k, n)
-        assert L.ggq_mmq_x64_unit_rows(Q8_0, b, k, n) == 64
+        assert L.ggq_mmq_x64_unit_rows(Q8_0, b, k, n) == want and L.ggq_mmq_x64_unit_rows(14, b, k, n) == 64   # (Q6_K: not an x64 format)
         if want == 96:
             tt = -(-b // 64)
             assert -(-n // 64) * tt > 256 >= -(-n // 96) * tt

@@ -51,13 +51,13 @@ def test_mmq_x64_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 mmq {t.name} b={batch}")
 
 
+@pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
 @pytest.mark.parametrize("dtype,batch,k,n_rows", [(torch.float16, 128, 1024, 8230), (torch.float32, 100, 1280, 8257), (torch.bfloat16, 256, 1024, 4100),
                                                   (torch.float16, 2048, 1024, 600), (torch.float16, 128, 4096, 8200)])
-def test_mmq_x64_96_row_units(oracle, dtype, batch, k, n_rows):
-    """launches that take the 96-row units (four two-row-tile waves + four one-row-tile waves per workgroup; Q4_K): against the oracle,
+def test_mmq_x64_96_row_units(oracle, t, dtype, batch, k, n_rows):
+    """launches that take the 96-row units (four two-row-tile waves + four one-row-tile waves per workgroup): against the oracle,
     with a last unit of 6 / 1 / 68 / 24 / 40 rows (the one-row-tile waves partly or not at all in the tensor); and a row's bits do not
     depend on the unit shape — the first rows equal the 64-row-unit launch of those rows alone"""
-    t = GGMLType.Q4_K
     L = ggqlib.hip()
     assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, n_rows) == 96
     w = synth.random_weight(t, n_rows, k, seed=batch + k)
@@ -66,7 +66,7 @@ def test_mmq_x64_96_row_units(oracle, dtype, batch, k, n_rows):
     bs, m_off = BLOCK[t][1], _F16_FIELDS[t][1]
     wb = w.reshape(n_rows, -1, bs)
     vals = np.array([6e-8, 1.0, 1023.5, 1024.5, 65504.0, -65504.0, -3.0, 0.0, -2000.0], np.float16)
-    for r in range(0, n_rows if dtype != torch.float16 else 0, 7):   # (fp16 outputs would overflow)
+    for r in range(0, n_rows if (dtype != torch.float16 and m_off is not None) else 0, 7):   # (fp16 outputs would overflow)
         for b in range(wb.shape[1]):
             wb[r, b, m_off:m_off + 2] = vals[(r + 5 * b) % len(vals)].reshape(1).view(np.uint8)
     w = wb.reshape(n_rows, -1)
