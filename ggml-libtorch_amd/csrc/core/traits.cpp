@@ -101,7 +101,7 @@ extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
 // the 64 x 64 wave-tile kernel (csrc/hip/mmq_x64.hip)
 extern "C" int ggq_mmq_x64_type_supported(int type) {
   switch (type) {
-    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q8_0: return 1;
+    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q4_0: return 1;
     default: return 0;
   }
 }

@@ -144,6 +144,14 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
       else
       x64_loop_q80(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                    sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+    } else if constexpr (T == GGQ_TYPE_Q4_0) {   // 144 bytes of a row per 256 elements (eight 18-byte blocks): one stage; both lane halves read the same bytes
+      const uint32_t hoff = 16u * (uint32_t)h;
+      if (one_tile)
+        x64_loop_q40_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+      else
+        x64_loop_q40(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                     sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else {
       const uint32_t hoff = 16u + 16u * (uint32_t)h;
       if (one_tile)
@@ -317,6 +325,7 @@ extern "C" int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type
   switch (type) {
     case GGQ_TYPE_Q4_K: return launch_x64_dt<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     case GGQ_TYPE_Q8_0: return launch_x64_dt<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
+    case GGQ_TYPE_Q4_0: return launch_x64_dt<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     default: return GGQ_ERR_TYPE;
   }
 }

@@ -152,6 +152,30 @@ class Q80_R1(Q80):
     STAGE = 32 * 144
 
 
+class Q40:
+    """Q4_0: 18-byte blocks {fp16 d; 16 bytes: element j = low nibble of byte j, element 16 + j = high nibble}.  One ring stage = 256 elements
+    = 8 blocks = 144 bytes of a row: Q4_K's two-stage ring and DMA scheme as they are.  A lane's K half IS a nibble plane (h = 0: the low
+    nibbles of the block's 16 bytes, h = 1: the high ones), so both lane halves read the same bytes — 18 g + 2 into the row's stage, through
+    two aligned chunk reads + v_alignbyte_b32 as Q8_0 — and the int8 operand is ((b ^ x) << s) & 0xF0 = 16 (n - 8), with the per-lane
+    constants x = 0x08 / 0x80 and s = 4 / 0; the row scale is d / 16."""
+    name, type_id = "q40", 2
+    BS = 144
+    CPR, DIV = 9, 7282
+    N_DMA = 10
+    STAGE = ROWS * 144
+    ROWS = ROWS
+
+
+class Q40_R1(Q40):
+    ROWS = 32
+    N_DMA = 5
+    STAGE = 32 * 144
+
+
+V_SH, V_XC = 212, 213        # Q4_0: per-lane shift (4 for the low-nibble half, 0 for the high one) and xor constant (0x08 / 0x80 per byte)
+S_MASKF0, S_SIXTEENTH, S_NEGM16 = 64, 78, 80   # Q4_0: 0xf0f0f0f0; s[78:79] = 0.0625 x 2; s[80:81] = -12582912 / 16 x 2
+
+
 F = Q4K
 R1 = False                  # one-row-tile schedule (gen_r1): the tiles of a group are ti = 0, 2 and alternate the result sets
 RAW8 = (192, 200)           # Q8_0: two aligned 16-byte chunks of the row's stage per row tile (the Q4_K header / min-term registers are free)
@@ -922,12 +946,238 @@ def gen_q80_r1(label):
     return a
 
 
+def q40_reads(a, rt, g):
+    """the two aligned chunks that hold block g's 16 quant bytes of this lane's row, and the block's d (g = 8, 9: blocks 0, 1 of the
+    next stage)"""
+    base_reg = V_LDSW if g < 8 else V_LDSWN
+    gl = g & 7
+    c = (18 * gl + 2) // 16
+    base = rt * 32 * 144
+    a.lds(f"ds_read_b128 {vr(RAW8[rt], 4)}, {vr(base_reg)} offset:{base + 16 * c}", f"raw{rt}x")
+    a.lds(f"ds_read_b128 {vr(RAW8[rt] + 4, 4)}, {vr(base_reg)} offset:{base + 16 * c + 16}", f"raw{rt}")
+    a.lds(f"ds_read_u16 {vr(DREG[rt][g & 1])}, {vr(base_reg)} offset:{base + 18 * gl}", f"d{rt}_{g & 1}")
+
+
+def q40_w_prep(a, rt, g):
+    """int8 operand of block g: the 16 quant bytes start (18 g + 2) % 16 bytes into the chunk pair; this lane half's nibbles -> 16 (n - 8)"""
+    a.wait_lg(f"raw{rt}")
+    sh = (18 * (g & 7) + 2) % 16
+    d0, rem = sh // 4, sh % 4
+    for i in range(4):
+        if rem:
+            a.i(f"v_alignbyte_b32 {vr(T_WHI + i)}, {vr(RAW8[rt] + i + d0 + 1)}, {vr(RAW8[rt] + i + d0)}, {rem}")
+        else:
+            a.i(f"v_xor_b32 {vr(T_WHI + i)}, {vr(V_XC)}, {vr(RAW8[rt] + i + d0)}")
+    if rem:
+        for i in range(4):
+            a.i(f"v_xor_b32 {vr(T_WHI + i)}, {vr(V_XC)}, {vr(T_WHI + i)}")
+    for i in range(4):
+        a.i(f"v_lshlrev_b32 {vr(T_WHI + i)}, {vr(V_SH)}, {vr(T_WHI + i)}")
+    for i in range(4):
+        a.i(f"v_and_b32 {vr(WOP[rt] + i)}, {sr(S_MASKF0)}, {vr(T_WHI + i)}")
+
+
+def q40_dw_prep(a, rt, g):
+    """row scale of block g: dw = d / 16 (the operand is 16 (n - 8)), nm = -12582912 * dw, as duplicated pairs"""
+    p = g & 1
+    a.wait_lg(f"d{rt}_{p}")
+    a.i(f"v_cvt_f32_f16_e32 {vr(T_DW)}, {vr(DREG[rt][p])}")
+    a.i(f"v_cvt_f32_f16_e32 {vr(T_DW + 1)}, {vr(DREG[rt][p])}")
+    a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 4 * p, 2)}, {vr(T_DW, 2)}, {sr(S_SIXTEENTH, 2)}")
+    a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 4 * p + 2, 2)}, {vr(T_DW, 2)}, {sr(S_NEGM16, 2)}")
+
+
+def q40_prologue_consts(a):
+    for s in (S_SIXTEENTH, S_SIXTEENTH + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0x3d800000")                    # 0.0625f
+    for s in (S_NEGM16, S_NEGM16 + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xc9400000")                    # -12582912 / 16 = -786432.0f
+    a.i(f"s_mov_b32 {sr(S_MASKF0)}, 0xf0f0f0f0")
+    a.i(f"v_lshrrev_b32 {vr(V_XC)}, 2, {vr(V_HOFF)}")             # hoff = 16 h -> 0 / 4
+    a.i(f"v_sub_u32 {vr(V_SH)}, 4, {vr(V_XC)}")                   # shift: 4 (low-nibble half) / 0
+    a.i(f"v_mov_b32 {vr(T_DW)}, 0x08080808")
+    a.i(f"v_lshlrev_b32 {vr(V_XC)}, {vr(V_XC)}, {vr(T_DW)}")      # xor constant: 0x08 / 0x80 per byte
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")                 # (ldsw0 = the row's stage base: both lane halves read the same bytes)
+    a.i(f"v_add_u32 {vr(V_LDSWN)}, {F.STAGE}, {vr(V_LDSW0)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_LDS)}")
+    a.i(f"s_add_u32 {sr(S_NSTAGE)}, {sr(S_LDS)}, {F.STAGE}")
+    a.i(f"s_mov_b32 {sr(S_WKN)}, {sr(S_WK)}")
+
+
+def q40_loop_end(a):
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
+    a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_NSTAGE)}")
+    a.i(f"s_mov_b32 {sr(S_NSTAGE)}, {sr(S_T0)}")
+    a.i(f"v_mov_b32 {vr(T_DW)}, {vr(V_LDSW)}")
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSWN)}")
+    a.i(f"v_mov_b32 {vr(V_LDSWN)}, {vr(T_DW)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+
+
+def q40_loop_top(a):
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
+
+
+def gen_q40(label):
+    """Q4_0: Q8_0's per-group pipeline (chunk-pair reads two groups ahead, operand one group ahead, the block's d beside them) on Q4_K's
+    two-stage ring (one stage = 256 elements, the next stage's ten DMA instructions in groups 0 .. 4)."""
+    global F
+    F = Q40
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    q40_prologue_consts(a)
+    for j in range(F.N_DMA):
+        dma_instr(a, j, S_STAGE)
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    d8_dma(a, 0, 0, False)
+    d8_dma(a, 1, 0, False)
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[1] + k)}, 0")
+    for k in range(8):
+        a.i(f"v_mov_b32 {vr(DWNM[1] + k)}, 0")
+    act_loads(a, 0)
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
+    a.wait_vm("dma")
+    a.wait_vm("d8dma0_1")
+    q40_reads(a, 0, 0)
+    q40_reads(a, 1, 0)
+    q40_w_prep(a, 0, 0)
+    q40_reads(a, 0, 1)
+    d8_reads(a, 0, 0)
+    q40_w_prep(a, 1, 0)
+    q40_reads(a, 1, 1)
+    Asm.armed = True
+    a.i(f"L_sb_{label}%=:")
+    vm0, lg0 = list(a.vm), list(a.lg)
+    q40_loop_top(a)
+    for g in range(8):
+        for ti in range(4):
+            rt = ti & 1
+            mfma(a, g, ti)
+            if ti < 2:
+                q40_dw_prep(a, ti, g)
+            if ti == 0:
+                act_loads(a, (g + 1) & 1)
+                advance_offsets(a, g)
+            if ti >= 2:
+                if (g, ti) == (6, 2):
+                    a.wait_vm("dma")             # the next stage has landed: its blocks 0, 1 are read in groups 6, 7
+                q40_w_prep(a, rt, g + 1)
+                q40_reads(a, rt, g + 2)
+            if g <= 4 and ti < 2 and 2 * g + ti < F.N_DMA:
+                dma_instr(a, 2 * g + ti, S_NSTAGE)
+            if g == 0 and ti >= 2:
+                d8_dma(a, ti - 2, 1, False)
+            if (g, ti) == (3, 2):
+                d8_dma(a, 0, 0, True)
+            if (g, ti) == (4, 0):
+                d8_dma(a, 1, 0, True)
+            pg, pti = (g, ti - 1) if ti else ((g - 1) % 8, 3)
+            fma_block(a, pg, pti)
+            if pti == 1:
+                d8_reads(a, 0, (pg + 1) % 8)
+            if pti == 3:
+                d8_reads(a, 1, (pg + 1) % 8)
+    q40_loop_end(a)
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
+    fma_block(a, 7, 3)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    F = Q4K
+    return a
+
+
+def gen_q40_r1(label):
+    """Q4_0, one row tile per wave: gen_q40 with two slots per group (as gen_q80_r1 is to gen_q80); the next stage's five DMA instructions
+    in groups 0 .. 2."""
+    global F, R1
+    F, R1 = Q40_R1, True
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    q40_prologue_consts(a)
+    for j in range(F.N_DMA):
+        dma_instr(a, j, S_STAGE)
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    d8_dma(a, 0, 0, False)
+    d8_dma(a, 1, 0, False)
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[1] + k)}, 0")
+    for k in range(4, 8):
+        a.i(f"v_mov_b32 {vr(DWNM[0] + k)}, 0")
+    act_loads(a, 0)
+    for s in (S_F0, S_F1):
+        a.i(f"s_add_u32 {sr(s)}, {sr(s)}, 0x400")
+    d8_dma(a, 0, 1, False)
+    d8_dma(a, 1, 1, False)
+    a.wait_vm("dma")
+    a.wait_vm("d8dma0_1")
+    q40_reads(a, 0, 0)
+    q40_w_prep(a, 0, 0)
+    q40_reads(a, 0, 1)
+    d8_reads(a, 0, 0)
+    Asm.armed = True
+    a.i(f"L_sb_{label}%=:")
+    vm0, lg0 = list(a.vm), list(a.lg)
+    q40_loop_top(a)
+    for g in range(8):
+        mfma(a, g, 0)
+        q40_dw_prep(a, 0, g)
+        act_loads(a, (g + 1) & 1)
+        advance_offsets(a, g)
+        for j in (2 * g, 2 * g + 1):
+            if j < F.N_DMA:
+                dma_instr(a, j, S_NSTAGE)
+        if g == 3:
+            d8_dma(a, 0, 0, True)
+        pg = (g - 1) % 8
+        fma_block(a, pg, 2)
+        d8_reads(a, 1, (pg + 1) % 8)
+        mfma(a, g, 2)
+        if g == 6:
+            a.wait_vm("dma")
+        q40_w_prep(a, 0, g + 1)
+        q40_reads(a, 0, g + 2)
+        if g == 3:
+            d8_dma(a, 1, 0, True)
+        if g == 7:
+            d8_dma(a, 0, 1, True)
+            d8_dma(a, 1, 1, True)
+        fma_block(a, g, 0)
+        d8_reads(a, 0, (g + 1) % 8)
+    q40_loop_end(a)
+    a.wait_lg("d8_1")
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
+    fma_block(a, 7, 2)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    F, R1 = Q4K, False
+    return a
+
+
 def emit(a, fn_name):
     asm = "\n".join(f'      "{l}\\n"' for l in a.lines)
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
     clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
     s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1,
-             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW}
+             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
     clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
     return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
 static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,
@@ -951,6 +1201,8 @@ if __name__ == "__main__":
     b = gen_q80("q80")
     c = gen_r1("r1_q4k_")
     d = gen_q80_r1("r1_q80_")
+    e4 = gen_q40("q40_")
+    f4 = gen_q40_r1("r1_q40_")
     if "--list" in sys.argv:
         print("\n".join((b if "q80" in sys.argv else c if "r1" in sys.argv else a).lines))
     with open(os.environ.get("X64_OUT", OUT), "w") as f:
@@ -958,4 +1210,6 @@ if __name__ == "__main__":
         f.write(emit(b, "x64_loop_q80"))
         f.write(emit(c, "x64_loop_q4k_r1"))
         f.write(emit(d, "x64_loop_q80_r1"))
+        f.write(emit(e4, "x64_loop_q40"))
+        f.write(emit(f4, "x64_loop_q40_r1"))
     print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)
