@@ -53,7 +53,7 @@ NAMES = {Q4_K: "Q4_K", Q4_0: "Q4_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q6_K: "Q6_K"}
 K_DIM, N_DIM, BATCH = 4096, 11008, 128
 COLD_BYTES = 352 << 20   # distinct bytes a "cold" ring must span: 256 MiB Infinity Cache + 32 MiB L2 + margin
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")
-ROOFLINE_KERNEL = "ggq::mmq_x64_kernel<Q4_K,f16,KS=4>"
+ROOFLINE_KERNEL = "ggq::mmq_x64_kernel<Q4_K,f16,KS=4,R3=true>"   # 96-row units: 230 workgroups of eight waves at the headline shape
 KERNEL_SOURCES = ("mmq_x64.hip", "mmq_x64_loops.inc")   # the traffic figure is refused when these changed since it was measured
 
 

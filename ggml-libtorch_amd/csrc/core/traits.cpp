@@ -257,7 +257,12 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // 1.04 - 1.23 at 168 - 192 units and 1.2 - 1.45 from 256 units on at every shape and K — one threshold on the unit count:
   //   11008 x 4096: b64 24.5 / 21.1   b128 31.2 / 29.4   b256 54.3 / 44.3   b1024 193 / 151      4096 x 4096: b128 17.1 / 20.3   b192 25.0 / 20.8
   //   4096 x 11008: b128 33.7 / 43.2   b192 53.4 / 43.9      3584 x 8192: b128 26.2 / 33.3   b192 41.9 / 34.2      28672 x 8192: b128 127 / 100
-  if (batch >= 33 && ggq_mmq_x64_supported(type, k, batch) && ((n_rows + 63) / 64) * ((batch + 63) / 64) >= 160) return GGQ_MMQ_ROUTE_X64;
+  // Re-measured with the 96-row units and for all three formats of the kernel (profiles/r04b_x64_vs_stream_{q4_k,q8_0,q4_0}.txt, streamed /
+  // x64, cold): from 168 units up Q4_K 1.15 - 1.45, Q8_0 1.43 - 1.6, Q4_0 1.37 - 1.55; at 96 - 128 units Q4_K 0.88 - 0.97, Q8_0 0.88 - 1.05
+  // (ahead warm, level cold), Q4_0 0.98 - 1.13 — Q4_0's streamed instance copies its 18-byte blocks through the texture path, so its
+  // threshold is 96 units; below 96 every format loses (0.68 - 0.95).
+  const int64_t x64_units = ((n_rows + 63) / 64) * ((batch + 63) / 64);
+  if (batch >= 33 && ggq_mmq_x64_supported(type, k, batch) && x64_units >= (type == GGQ_TYPE_Q4_0 ? 96 : 160)) return GGQ_MMQ_ROUTE_X64;
   // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):
   // the dot4 kernel while it beats the streamed one with the weights coming from HBM, the barrier-coupled LDS-tile
   // kernel for the mid batches of the two formats whose streamed instance is bound by its weight copy, streamed beyond.

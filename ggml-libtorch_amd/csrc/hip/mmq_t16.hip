@@ -748,6 +748,8 @@ static int launch_t16_t(const void* w, const void* q8, void* y, int dt, int64_t 
 namespace ggq {
 int mul_mat_q_stream_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
                           int64_t ldy, int epilogue, const void* aux, void* stream, const void* go);   // mmq.hip
+int mul_mat_q_x64_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
+                       int64_t ldy, int epilogue, const void* aux, void* stream, const void* go);   // mmq_x64.hip
 int mul_mat_q_t16_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
                        int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream, const void* go);
 }
@@ -766,7 +768,7 @@ extern "C" int ggq_mul_mat_q_gather(const void* w, const void* x, void* const* d
   if (batch < 0 || k <= 0 || n_rows < 0) return GGQ_ERR_ARG;
   if (batch == 0 || n_rows == 0) return GGQ_ERR_SHAPE;   // nothing would publish the flags
   const int route = ggq_mmq_route(type, batch, k, n_rows);
-  if (route != GGQ_MMQ_ROUTE_T16 && route != GGQ_MMQ_ROUTE_STREAM) return ggq_mmq_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
+  if (route != GGQ_MMQ_ROUTE_T16 && route != GGQ_MMQ_ROUTE_STREAM && route != GGQ_MMQ_ROUTE_X64) return ggq_mmq_type_supported(type) ? GGQ_ERR_SHAPE : GGQ_ERR_TYPE;
   GatherOut go{};
   for (int d = 0; d < n_dst; ++d) {
     if (!dsts[d]) return GGQ_ERR_ARG;
@@ -787,6 +789,11 @@ extern "C" int ggq_mul_mat_q_gather(const void* w, const void* x, void* const* d
   go.n_dst = n_dst;
   go.n_flag = n_flag;
   if (!w || !x || !scratch) return GGQ_ERR_ARG;
+  if (route == GGQ_MMQ_ROUTE_X64) {   // the 64 x 64 wave-tile kernel: a workgroup arrives once its stores have drained
+    const int rc = ggq_quantize_q8_1_x64(x, dtype, scratch, batch, k, type, stream);
+    if (rc != GGQ_OK) return rc;
+    return mul_mat_q_x64_impl(w, scratch, dsts[0], type, dtype, batch, k, n_rows, ldy, GGQ_EPI_NONE, nullptr, stream, &go);
+  }
   if (route == GGQ_MMQ_ROUTE_STREAM) {   // the streamed kernel: every wave that stores arrives, the last arrival publishes
     const int rc = ggq_quantize_q8_1_tiled(x, dtype, scratch, batch, k, type, stream);
     if (rc != GGQ_OK) return rc;

@@ -34,7 +34,7 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 #endif
 #include GGQ_X64_LOOPS_INC
 
-struct X64Epilogue { int kind; const void* aux; };
+struct X64Epilogue { int kind; const void* aux; GatherOut go; };
 }  // namespace ggq
 
 #ifndef GGQ_X64_STAMP
@@ -86,7 +86,7 @@ template <int T, int DT, int KS, bool R3>
 __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
                                                          void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
                                                          int n_tok_tiles, int n_units, int per_xcd, int epi,
-                                                         const void* __restrict__ aux) {
+                                                         const void* __restrict__ aux, GatherOut go) {
   static_assert(!R3 || KS == 4, "96-row units: four K-slices");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
   constexpr int RPT = UROWS * 64 / NTHR;   // rows per thread: 16 (four waves), 8 (eight), 12 (96-row units)
   const int tl64 = tid / (UROWS / RPT), rb = (tid % (UROWS / RPT)) * RPT;
   const int t = t0 + tl64;
-  if (t >= batch) return;
+  if (t < batch) {
   const int tt = tl64 >> 5, tl = tl64 & 31;
   const int i_reg = 4 * (tl >> 3) + (tl & 3), hh = (tl >> 2) & 1;
   float v[RPT];
@@ -241,17 +241,45 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
       dst[0] = v2i{(int)pk[0], (int)pk[1]};
       dst[1] = v2i{(int)pk[2], (int)pk[3]};
       dst[2] = v2i{(int)pk[4], (int)pk[5]};
+      for (int d = 1; d < go.n_dst; ++d)   // (kernel-uniform) the peers' slots: system-coherent write-through stores
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const v2i val{(int)pk[2 * c], (int)pk[2 * c + 1]};
+          asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"((uint16_t*)go.dst[d] + yi0 + 4 * c), "v"(val) : "memory");
+        }
     } else {
       v4i* dst = (v4i*)((uint16_t*)y + yi0);
       dst[0] = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
       if constexpr (RPT == 16) dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
+      for (int d = 1; d < go.n_dst; ++d)
+#pragma unroll
+        for (int c = 0; c < RPT / 8; ++c) {
+          const v4i val{(int)pk[4 * c], (int)pk[4 * c + 1], (int)pk[4 * c + 2], (int)pk[4 * c + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"((uint16_t*)go.dst[d] + yi0 + 8 * c), "v"(val) : "memory");
+        }
     }
   } else {
 #pragma unroll
     for (int e = 0; e < RPT; ++e)
-      if (row0 + e < n_rows) Elem<DT>::st(y, yi0 + e, v[e]);
+      if (row0 + e < n_rows) {
+        Elem<DT>::st(y, yi0 + e, v[e]);
+        gather_store<DT>(go, yi0 + e, v[e]);
+      }
   }
+  }   // t < batch
   X64_STAMP(5);
+  if (go.n_flag > 0) {   // (kernel-uniform) multi-destination launch: the workgroup's stores drain (write-through: complete at vmcnt 0), it
+    // arrives; the last of the launch's n_units arrivals writes the flags — the one release at system scope (as mmq_t16.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t before = __hip_atomic_fetch_add(go.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (uint32_t)n_units - 1u) {
+        __hip_atomic_store(go.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int d = 0; d < go.n_flag; ++d) __hip_atomic_store(go.flag[d], go.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 template <int T, int DT>
@@ -274,7 +302,7 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64_LDS_R3) != hipSuccess) return GGQ_ERR_LAUNCH;
       GGQ_HIP_PRE_LAUNCH();
       hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64_LDS_R3, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                         (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+                         (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
       GGQ_HIP_CHECK_LAUNCH();
       return GGQ_OK;
     }
@@ -284,13 +312,13 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<8>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
     GGQ_HIP_PRE_LAUNCH();
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64Lds<8>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
   } else {
     auto kern = mmq_x64_kernel<T, DT, 4, false>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<4>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
     GGQ_HIP_PRE_LAUNCH();
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), X64Lds<4>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux);
+                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
   }
   GGQ_HIP_CHECK_LAUNCH();
   return GGQ_OK;
@@ -309,8 +337,19 @@ static int launch_x64_dt(const void* w, const void* q8, void* y, int dt, int64_t
 
 }  // namespace ggq
 
+namespace ggq {
+int mul_mat_q_x64_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
+                       int64_t ldy, int epilogue, const void* aux, void* stream, const void* go);
+}
+
 extern "C" int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k,
                                  int64_t n_rows, int64_t ldy, int epilogue, const void* aux, void* stream) {
+  return ggq::mul_mat_q_x64_impl(w, q, y, type, dtype, batch, k, n_rows, ldy, epilogue, aux, stream, nullptr);
+}
+
+// go != nullptr: with the multi-destination write-back (ggq_mul_mat_q_gather)
+int ggq::mul_mat_q_x64_impl(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
+                            int64_t ldy, int epilogue, const void* aux, void* stream, const void* go) {
   using namespace ggq;
   if (epilogue < GGQ_EPI_NONE || epilogue > GGQ_EPI_SILU_MUL || (epilogue != GGQ_EPI_NONE && !aux)) return GGQ_ERR_ARG;
   if (k <= 0 || n_rows < 0 || batch < 0 || ldy < n_rows) return GGQ_ERR_ARG;
@@ -321,7 +360,7 @@ extern "C" int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type
   if (!ggq_mmq_x64_supported(type, k, batch)) return GGQ_ERR_SHAPE;
   if (!w || !q || !y) return GGQ_ERR_ARG;
   if (((uintptr_t)w & 1) || ((uintptr_t)q & 15)) return GGQ_ERR_ALIGN;
-  const X64Epilogue ep{epilogue, aux};
+  const X64Epilogue ep{epilogue, aux, go ? *(const GatherOut*)go : GatherOut{}};
   switch (type) {
     case GGQ_TYPE_Q4_K: return launch_x64_dt<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     case GGQ_TYPE_Q8_0: return launch_x64_dt<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);

@@ -296,7 +296,8 @@ int ggq_peer_wait(const void* flags, int n_src, uint32_t generation, void* statu
  * every workgroup has released its stores at system scope `generation` is written into flags[0 .. n_flag) (ggq_peer_wait on the
  * consumer side, as after ggq_peer_scatter; `arrivals` as there).  dsts / flags: HOST arrays of device pointers, at most 8 each.
  * For the (type, batch, shape) ggq_mmq_route() sends to the 16-token-tile kernel (GGQ_MMQ_ROUTE_T16: the last workgroup publishes) or
- * to the streamed kernel (GGQ_MMQ_ROUTE_STREAM: every wave that stores arrives, the last arrival publishes); GGQ_ERR_SHAPE
+ * to the streamed kernel (GGQ_MMQ_ROUTE_STREAM: every wave that stores arrives, the last arrival publishes) or to the 64 x 64 wave-tile
+ * kernel (GGQ_MMQ_ROUTE_X64: a workgroup arrives once its stores have drained); GGQ_ERR_SHAPE
  * otherwise — the caller then falls back to ggq_mul_mat_q_ld into its own slot + ggq_peer_scatter.
  * ggq_mul_mat_vec_q_gather: the same for one token — the fused GEMV (ggq_mul_mat_vec_q) storing its n_rows outputs into
  * dsts[0 .. n_dst) and publishing from its last wave; every format of ggq_mul_mat_vec_q. */

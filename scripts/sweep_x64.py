@@ -1,4 +1,4 @@
-"""x64 op (quantise + 64 x 64 wave-tile kernel) against the op ggq_mul_mat_q runs today, over shapes and batches, warm / cold.
+"""x64 op (quantise + 64 x 64 wave-tile kernel) against the streamed op (its own quantiser + kernel), over shapes and batches, warm / cold.
 usage: python scripts/sweep_x64.py [type=12] > profiles/r04_x64_vs_stream_*.txt"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +28,7 @@ def timeit(fn, iters):
         ts.append(e0.elapsed_time(e1) * 1e3 / iters)
     return float(np.median(ts))
 
-print(f"# type {t}: op us warm / cold, current route | x64; ratio = current / x64 (cold)")
+print(f"# type {t}: op us warm / cold, streamed kernel (route 3) | x64; ratio = streamed / x64 (cold)")
 for (N, K) in SHAPES:
     w0 = torch.from_numpy(synth.random_weight(t, N, K, seed=0)).cuda()
     ring = [w0] + [w0.clone() for _ in range(max(1, (352 << 20) // w0.numel()))]
@@ -40,13 +40,14 @@ for (N, K) in SHAPES:
         def x64_op(i, r=ring):
             L.ggq_quantize_q8_1_x64(vp(x), 1, vp(scr), b, K, t, st())
             L.ggq_mul_mat_q_x64(vp(r[i % len(r)]), vp(scr), vp(y), t, 1, b, K, N, N, 0, None, st())
-        def old_op(i, r=ring):
-            L.ggq_mul_mat_q(vp(r[i % len(r)]), vp(x), vp(y), t, 1, b, K, N, vp(scr), st())
+        def old_op(i, r=ring):   # the streamed kernel with its own quantiser (what the route takes below the x64 threshold), whatever the route says now
+            L.ggq_quantize_q8_1_tiled(vp(x), 1, vp(scr), b, K, t, st())
+            L.ggq_mul_mat_q_pretiled(vp(r[i % len(r)]), vp(scr), vp(y), t, 1, b, K, N, N, st())
         if os.environ.get("X64_ONLY"):
             xw, xc = timeit(lambda i: x64_op(i, [w0]), iters), timeit(x64_op, iters)
             print(f"{N:6d} x {K:5d} batch {b:5d}: units {-(-N // 64) * -(-b // 64):5d} x64 {xw:8.1f} / {xc:8.1f}", flush=True)
             continue
         ow, oc = timeit(lambda i: old_op(i, [w0]), iters), timeit(old_op, iters)
         xw, xc = timeit(lambda i: x64_op(i, [w0]), iters), timeit(x64_op, iters)
-        print(f"{N:6d} x {K:5d} batch {b:5d}: route {L.ggq_mmq_route(t, b, K, N)} {ow:8.1f} / {oc:8.1f} | {xw:8.1f} / {xc:8.1f}   ratio {oc / xc:5.2f} (warm {ow / xw:5.2f})", flush=True)
+        print(f"{N:6d} x {K:5d} batch {b:5d}: route 3 {ow:8.1f} / {oc:8.1f} | {xw:8.1f} / {xc:8.1f}   ratio {oc / xc:5.2f} (warm {ow / xw:5.2f})", flush=True)
     del ring, w0

@@ -48,7 +48,10 @@ def main():
     L = ggqlib.hip()
     cases = [(t, 8, n_rows, torch.float16, 4), (t, 40, n_rows, torch.float16, 3), (t, 128, 200 * world, torch.float16, 3),
              (t, 1, n_rows, torch.float16, None), (t, 1, 1376 * world, torch.float16, None), (GGMLType.Q8_0, 128, 72 * world, torch.float32, 3),
-             (GGMLType.Q6_K, 48, 40 * world, torch.bfloat16, 3), (GGMLType.Q2_K, 2, n_rows, torch.float16, 1)]
+             (GGMLType.Q6_K, 48, 40 * world, torch.bfloat16, 3), (GGMLType.Q2_K, 2, n_rows, torch.float16, 1),
+             # the 64 x 64 wave-tile kernel: 64-row units (four K-slices at K = 1024), fp16 16-byte and fp32 scalar peer stores, a ragged last unit
+             (GGMLType.Q4_0, 640, 616 * world, torch.float16, 5), (t, 1280, 520 * world, torch.float32, 5),
+             (t, 2048, 608 * world, torch.float16, 5)]   # (96-row units: 8-byte peer stores)
     for (t2, b2, n2, dt2, want_route) in cases:
         w2 = synth.random_weight(t2, n2, k, seed=21 + b2)
         s2, e2 = shard_rows(n2, world, rank)
