@@ -113,11 +113,24 @@ extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
 // rows of one unit: 96 (four two-row-tile waves + four one-row-tile waves, one workgroup per CU) where the launch then is ONE round of
 // at most 256 workgroups while 64-row units would put two workgroups on some CUs and one on the others (the two-workgroup CUs finish
 // 40-60 % later: profiles/r04_x64_stamps.txt; the sweep behind the rule: profiles/r04_x64_unit_rows.txt)
+// 32 (every wave a one-row-tile wave: twice the units, half the work each) where the launch has fewer than 160 units of 64 rows — too few
+// to fill the chip; against the better of the streamed kernel and 64-row units (profiles/r04b_x64_unit_rows32_*.txt, cold): Q8_0 0.75 - 0.96
+// and Q4_0 0.76 - 0.93 from 32 units of 64 up, Q4_K 0.87 - 0.94 at 96 - 128 units (level with the streamed kernel below) and 1.03 - 1.2 from
+// 168 units on for all three, where 64- / 96-row units stay.  Bit-identical to the other unit shapes (same loops, same slice order).
 extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows) {
-  if (!ggq_mmq_x64_type_supported(type) || k < 4 * 256) return 64;
+  if (!ggq_mmq_x64_type_supported(type)) return 64;
   const int64_t tt = (batch + 63) / 64;
   const int64_t u64 = ((n_rows + 63) / 64) * tt, u96 = ((n_rows + 95) / 96) * tt;
-  return u64 > 256 && u96 <= 256 ? 96 : 64;
+  if (u64 < 160) return 32;
+  return k >= 4 * 256 && u64 > 256 && u96 <= 256 ? 96 : 64;
+}
+// fewest 32-row units from which the route takes the x64 kernel below 160 units of 64 rows (0: never)
+static int64_t x64_min_units32(int type) {
+  switch (type) {
+    case GGQ_TYPE_Q4_K: return 192;
+    case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q4_0: return 64;
+    default: return 0;
+  }
 }
 
 extern "C" int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch) {
@@ -259,10 +272,12 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   //   4096 x 11008: b128 33.7 / 43.2   b192 53.4 / 43.9      3584 x 8192: b128 26.2 / 33.3   b192 41.9 / 34.2      28672 x 8192: b128 127 / 100
   // Re-measured with the 96-row units and for all three formats of the kernel (profiles/r04b_x64_vs_stream_{q4_k,q8_0,q4_0}.txt, streamed /
   // x64, cold): from 168 units up Q4_K 1.15 - 1.45, Q8_0 1.43 - 1.6, Q4_0 1.37 - 1.55; at 96 - 128 units Q4_K 0.88 - 0.97, Q8_0 0.88 - 1.05
-  // (ahead warm, level cold), Q4_0 0.98 - 1.13 — Q4_0's streamed instance copies its 18-byte blocks through the texture path, so its
-  // threshold is 96 units; below 96 every format loses (0.68 - 0.95).
-  const int64_t x64_units = ((n_rows + 63) / 64) * ((batch + 63) / 64);
-  if (batch >= 33 && ggq_mmq_x64_supported(type, k, batch) && x64_units >= (type == GGQ_TYPE_Q4_0 ? 96 : 160)) return GGQ_MMQ_ROUTE_X64;
+  // (ahead warm, level cold), Q4_0 0.98 - 1.13; below 96 units of 64 rows every format loses with 64-row units (0.68 - 0.95).
+  // Below 160 units the kernel's 32-row units (ggq_mmq_x64_unit_rows) take over from the band where they beat the streamed kernel.
+  const int64_t x64_units = ((n_rows + 63) / 64) * ((batch + 63) / 64), x32_units = ((n_rows + 31) / 32) * ((batch + 63) / 64);
+  if (batch >= 33 && ggq_mmq_x64_supported(type, k, batch) &&
+      (x64_units >= 160 || (x64_min_units32(type) > 0 && x32_units >= x64_min_units32(type))))
+    return GGQ_MMQ_ROUTE_X64;
   // The other formats (and batch 1 through this entry point), thresholds measured at 11008 x 4096 (rounds 1-2, mmq.hip):
   // the dot4 kernel while it beats the streamed one with the weights coming from HBM, the barrier-coupled LDS-tile
   // kernel for the mid batches of the two formats whose streamed instance is bound by its weight copy, streamed beyond.

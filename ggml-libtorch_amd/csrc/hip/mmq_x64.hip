@@ -82,23 +82,27 @@ constexpr int X64_STAGE_R1 = 32 * 144;
 constexpr int X64_WAVE_LDS_R1 = 2 * X64_STAGE_R1 + 2048;
 constexpr int X64_LDS_R3 = 4 * X64_WAVE_LDS + 4 * X64_WAVE_LDS_R1;
 
-template <int T, int DT, int KS, bool R3>
-__global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
+// UR = weight rows per unit: 64; 96 (R3, above); 32 (U32: every wave a one-row-tile wave — the form for launches with too few 64-row
+// units to fill the chip: twice the units, half the work each; ggq_mmq_x64_unit_rows)
+template <int T, int DT, int KS, int UR>
+__global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
                                                          void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
                                                          int n_tok_tiles, int n_units, int per_xcd, int epi,
                                                          const void* __restrict__ aux, GatherOut go) {
+  constexpr bool R3 = UR == 96, U32 = UR == 32;
+  static_assert(UR == 32 || UR == 64 || UR == 96, "unit rows");
   static_assert(!R3 || KS == 4, "96-row units: four K-slices");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
   if (unit >= n_units) return;
-  constexpr int UROWS = R3 ? 96 : 64;
+  constexpr int UROWS = UR;
   const int row_tile = unit / n_tok_tiles, tok_tile = unit % n_tok_tiles;
   const int t0 = tok_tile * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool one_tile = R3 && wave >= 4;                  // the wave kind with one row tile (rows 64-95 of the unit)
+  const bool one_tile = U32 || (R3 && wave >= 4);         // the wave kind with one row tile (R3: rows 64-95 of the unit)
   const int ks = R3 ? (wave & 3) : wave;
-  const int n0 = row_tile * UROWS, nb = n0 + (one_tile ? 64 : 0);
+  const int n0 = row_tile * UROWS, nb = n0 + (R3 && one_tile ? 64 : 0);
   const int r = lane & 31, h = lane >> 5;
   const int n_sb = k / 256;
   const int sb_begin = (int)((int64_t)ks * n_sb / KS), sb_end = (int)((int64_t)(ks + 1) * n_sb / KS);
@@ -129,7 +133,8 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
     const uint32_t n_tt32 = 2u * (uint32_t)n_tok_tiles;                  // 32-token records per super-block
     const uint32_t sbstride = n_tt32 * X64_REC;
     const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
-    const uint32_t ring = (uint32_t)(uintptr_t)lds + (one_tile ? 4u * X64_WAVE_LDS + (uint32_t)ks * X64_WAVE_LDS_R1 : (uint32_t)ks * X64_WAVE_LDS);
+    const uint32_t ring = (uint32_t)(uintptr_t)lds + (U32 ? (uint32_t)ks * X64_WAVE_LDS_R1
+                                                           : one_tile ? 4u * X64_WAVE_LDS + (uint32_t)ks * X64_WAVE_LDS_R1 : (uint32_t)ks * X64_WAVE_LDS);
     // LDS-DMA source offset of this lane inside the seven rows one instruction copies: row lane / 9, 16-byte chunk lane % 9
     // (lane 63 = chunk 0 of the next instruction's first row: both write the same bytes)
     const uint32_t dmaoff = (uint32_t)(lane / 9) * row_bytes + (uint32_t)(lane % 9) * 16u;
@@ -169,7 +174,7 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
   __syncthreads();
   X64_STAMP(3);
   float* red = (float*)lds;
-  float* red1 = red + KS * 4096;
+  float* red1 = U32 ? red : red + KS * 4096;
   if (!one_tile) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
   // thread -> (token tl64 of the unit, RPT consecutive rows): lane (row r, half h) of tile (rt, tt) holds token 32 tt + 8 (i >> 2) + 4 h + (i & 3)
   // of row 32 rt + r in register i, so four consecutive rows of one token are four consecutive floats of red[]
   constexpr int NTHR = R3 ? 512 : 64 * KS;
-  constexpr int RPT = UROWS * 64 / NTHR;   // rows per thread: 16 (four waves), 8 (eight), 12 (96-row units)
+  constexpr int RPT = UROWS * 64 / NTHR;   // rows per thread: 16 (four waves), 8 (eight), 12 (96-row units), 8 / 4 (32-row units)
   const int tl64 = tid / (UROWS / RPT), rb = (tid % (UROWS / RPT)) * RPT;
   const int t = t0 + tl64;
   if (t < batch) {
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
   for (int j = 0; j < RPT / 4; ++j) {
     const int R = rb + 4 * j, rt = R >> 5, rr = R & 31;
     v4f s;
-    if (R3 && rt == 2) {
+    if (U32 || (R3 && rt == 2)) {
       s = *(const v4f*)(red1 + (((0 * 2 + tt) * 16 + i_reg) * 64 + 32 * hh + rr));
 #pragma unroll
       for (int sl = 1; sl < KS; ++sl) s += *(const v4f*)(red1 + (((sl * 2 + tt) * 16 + i_reg) * 64 + 32 * hh + rr));
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
     for (int e = 0; e < RPT; ++e)
       if (row0 + e < n_rows) v[e] = x64_apply_epilogue<DT>(v[e], epi, aux, yi0 + e, row0 + e);
   }
-  // 16-byte stores of eight fp16 / bf16 rows; the 12-row threads of the 96-row units (row0 a multiple of 12: 8-byte aligned) store 8 + 8 + 8 bytes
+  // 16-byte stores of eight fp16 / bf16 rows; the 12- and 4-row threads (96-row units; 32-row units with eight slices) store 8 bytes at a time
   const bool vec_ok = DT != GGQ_F32 && (ldy & 7) == 0 && ((uintptr_t)y & 15) == 0 && row0 + RPT <= n_rows;
   if (vec_ok) {
     uint32_t pk[RPT / 2];
@@ -236,14 +241,13 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
       }
       pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
     }
-    if constexpr (RPT == 12) {
+    if constexpr (RPT == 12 || RPT == 4) {
       v2i* dst = (v2i*)((uint16_t*)y + yi0);
-      dst[0] = v2i{(int)pk[0], (int)pk[1]};
-      dst[1] = v2i{(int)pk[2], (int)pk[3]};
-      dst[2] = v2i{(int)pk[4], (int)pk[5]};
+#pragma unroll
+      for (int c = 0; c < RPT / 4; ++c) dst[c] = v2i{(int)pk[2 * c], (int)pk[2 * c + 1]};
       for (int d = 1; d < go.n_dst; ++d)   // (kernel-uniform) the peers' slots: system-coherent write-through stores
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < RPT / 4; ++c) {
           const v2i val{(int)pk[2 * c], (int)pk[2 * c + 1]};
           asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"((uint16_t*)go.dst[d] + yi0 + 4 * c), "v"(val) : "memory");
         }
@@ -282,46 +286,41 @@ __global__ void __launch_bounds__(R3 ? 512 : 64 * KS, R3 ? 1 : 2) mmq_x64_kernel
   }
 }
 
+template <int T, int DT, int KS, int UR>
+static int launch_x64_inst(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
+                           const X64Epilogue& ep, int64_t n_tok_tiles, int64_t n_units) {
+  constexpr int LDS = UR == 96 ? X64_LDS_R3 : UR == 32 ? KS * X64_WAVE_LDS_R1 : X64Lds<KS>::BYTES;
+  constexpr int NTHR = UR == 96 ? 512 : 64 * KS;
+  const int64_t per_xcd = (n_units + 7) / 8;
+  auto kern = mmq_x64_kernel<T, DT, KS, UR>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
+  GGQ_HIP_PRE_LAUNCH();
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NTHR), LDS, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
+                     (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
+  GGQ_HIP_CHECK_LAUNCH();
+  return GGQ_OK;
+}
+
 template <int T, int DT>
 static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
                       X64Epilogue ep) {
   const int64_t n_tok_tiles = (batch + 63) / 64;
-  // -DGGQ_TUNING builds only (scripts/sweep_x64.py): GGQ_X64_KS forces 4 or 8 K-slices, GGQ_X64_ROWS 64- or 96-row units
+  // -DGGQ_TUNING builds only (scripts/sweep_x64.py): GGQ_X64_KS forces 4 or 8 K-slices, GGQ_X64_ROWS 32- / 64- / 96-row units
   static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");
   static const char* er = GGQ_TUNING_ENV("GGQ_X64_ROWS");
-  const int unit_rows = er && (er[0] == '6' || er[0] == '9') ? (er[0] == '9' ? 96 : 64) : ggq_mmq_x64_unit_rows(T, batch, k, n);
+  const int unit_rows = er && (er[0] == '3' || er[0] == '6' || er[0] == '9') ? (er[0] == '9' ? 96 : er[0] == '3' ? 32 : 64)
+                                                                             : ggq_mmq_x64_unit_rows(T, batch, k, n);
   const int64_t n_units = ((n + unit_rows - 1) / unit_rows) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
-  const int64_t per_xcd = (n_units + 7) / 8;
+  if (unit_rows == 96) return launch_x64_inst<T, DT, 4, 96>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
   // at most one unit per CU: eight K-slices per unit (two waves per SIMD either way, half the K loop per wave); otherwise four, two
-  // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable)
-  const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : ggq_mmq_x64_k_slices(batch, k, n);
-  {
-    if (unit_rows == 96) {
-      auto kern = mmq_x64_kernel<T, DT, 4, true>;
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64_LDS_R3) != hipSuccess) return GGQ_ERR_LAUNCH;
-      GGQ_HIP_PRE_LAUNCH();
-      hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64_LDS_R3, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                         (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
-      GGQ_HIP_CHECK_LAUNCH();
-      return GGQ_OK;
-    }
-  }
-  if (ks == 8 && k >= 8 * 256) {
-    auto kern = mmq_x64_kernel<T, DT, 8, false>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<8>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
-    GGQ_HIP_PRE_LAUNCH();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(512), X64Lds<8>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
-  } else {
-    auto kern = mmq_x64_kernel<T, DT, 4, false>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X64Lds<4>::BYTES) != hipSuccess) return GGQ_ERR_LAUNCH;
-    GGQ_HIP_PRE_LAUNCH();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(256), X64Lds<4>::BYTES, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
-                       (int)batch, ldy, (int)n_tok_tiles, (int)n_units, (int)per_xcd, ep.kind, ep.aux, ep.go);
-  }
-  GGQ_HIP_CHECK_LAUNCH();
-  return GGQ_OK;
+  // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable; for 32-row units the same rule on their count)
+  const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : (n_units <= 256 && k >= 8 * 256 ? 8 : 4);
+  if (unit_rows == 32)
+    return ks == 8 ? launch_x64_inst<T, DT, 8, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
+                   : launch_x64_inst<T, DT, 4, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
+  return ks == 8 && k >= 8 * 256 ? launch_x64_inst<T, DT, 8, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
+                                 : launch_x64_inst<T, DT, 4, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
 }
 
 template <int T>

@@ -16,12 +16,12 @@ if os.environ.get("CHILD"):
     from ggq.synth import _F16_FIELDS
     ggqlib._hip = ggqlib._bind(ctypes.CDLL(os.environ["GGQ_LIB"]), ggqlib.HIP_SYMBOLS)
     import util
-    t = 12
+    t = int(os.environ.get("TYPE", "12"))
     w = synth.random_weight(t, N, K, seed=B + K)
     bs, m_off = BLOCK[t][1], _F16_FIELDS[t][1]
     wb = w.reshape(N, -1, bs)
     vals = np.array([6e-8, 1.0, 1023.5, 1024.5, 65504.0, -65504.0, -3.0, 0.0, -2000.0], np.float16)
-    if PATCH:
+    if PATCH and m_off is not None:
         for r in range(0, N, 7):
             for b in range(wb.shape[1]):
                 wb[r, b, m_off:m_off + 2] = vals[(r + 5 * b) % len(vals)].reshape(1).view(np.uint8)
@@ -32,11 +32,12 @@ if os.environ.get("CHILD"):
     sys.exit(0)
 from collections import Counter
 ys = {}
-for rows in ("96", "64"):
+RA, RB = os.environ.get("ROWS_AB", "96,64").split(",")
+for rows in (RA, RB):
     f = f"/tmp/dbg_r3b_{rows}.npy"
     subprocess.run([sys.executable, __file__] + sys.argv[1:], env=dict(os.environ, CHILD=f, GGQ_X64_ROWS=rows), check=True)
     ys[rows] = np.load(f)
-d = ys["96"] != ys["64"]
+d = ys[RA] != ys[RB]
 print(f"{N} x {K} batch {B} patch {PATCH}: {d.sum()} of {d.size} differ")
 if d.any():
     tok, row = np.nonzero(d)
@@ -44,7 +45,7 @@ if d.any():
     print("rows mod 7 == 0:", int((row % 7 == 0).sum()), "of", len(row))
     print("tokens:", sorted(Counter((tok % 64).tolist()).items())[:70])
     print("units:", sorted(Counter((row // 96).tolist()).items())[:10])
-    rel = np.abs(ys["96"][d] - ys["64"][d]) / (np.abs(ys["64"][d]) + 1e-9)
+    rel = np.abs(ys[RA][d] - ys[RB][d]) / (np.abs(ys[RB][d]) + 1e-9)
     print("rel diff median %.3g max %.3g" % (np.median(rel), rel.max()))
     for i in range(min(8, len(row))):
-        print("  tok", tok[i], "row", row[i], ys["96"][tok[i], row[i]], ys["64"][tok[i], row[i]])
+        print("  tok", tok[i], "row", row[i], ys[RA][tok[i], row[i]], ys[RB][tok[i], row[i]])

@@ -60,6 +60,7 @@ def test_mmq_routing_table():
     L = ggqlib.cpu()
     NONE, DOT4, LDS_TILE, STREAM, T16, X64 = range(6)
     units64 = lambda b, n: -(-n // 64) * -(-b // 64)
+    units32 = lambda b, n: -(-n // 32) * -(-b // 64)
     Q4_K, Q5_K, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q6_K, Q3_K = 12, 13, 2, 3, 6, 7, 8, 14, 11
     shapes = [(4096, 11008), (11008, 4096), (8192, 3584), (8192, 28672), (256, 16), (4096 + 32, 64)]
     for k, n in shapes:
@@ -71,10 +72,12 @@ def test_mmq_routing_table():
                     assert r == NONE
                     continue
                 assert r in (DOT4, LDS_TILE, STREAM, T16, X64)
-                x64_from = 96 if int(t) == Q4_0 else 160
-                if r == X64:   # the 64 x 64 wave tiles: from 33 tokens, where the launch has at least 160 units (Q4_0: 96), for the formats the kernel serves
-                    assert b >= 33 and k % 256 == 0 and units64(b, n) >= x64_from and L.ggq_mmq_x64_supported(int(t), k, b) == 1
-                elif b >= 33 and k % 256 == 0 and units64(b, n) >= x64_from:
+                # the 64 x 64 wave tiles: from 33 tokens, where the launch has at least 160 units of 64 rows — or, with the kernel's 32-row
+                # units, at least 192 (Q4_K) / 64 (Q8_0, Q4_0) units of 32 rows — for the formats the kernel serves
+                big_enough = units64(b, n) >= 160 or units32(b, n) >= {Q4_K: 192, Q8_0: 64, Q4_0: 64}.get(int(t), 1 << 62)
+                if r == X64:
+                    assert b >= 33 and k % 256 == 0 and big_enough and L.ggq_mmq_x64_supported(int(t), k, b) == 1
+                elif b >= 33 and k % 256 == 0 and big_enough:
                     assert L.ggq_mmq_x64_supported(int(t), k, b) == 0
                 if r == T16:
                     assert k % 256 == 0 and (1 if n < 8192 else 2) <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
@@ -89,10 +92,10 @@ def test_mmq_routing_table():
         two = T16 if n in (11008, 4096, 3584) else STREAM
         assert L.ggq_mmq_route(Q4_K, 32, k, n) == two and L.ggq_mmq_route(Q5_K, 17, k, n) == two
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
-        assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if n >= 64 * 160 else STREAM)
-        assert L.ggq_mmq_route(Q4_K, 128, k, n) == (X64 if n >= 64 * 80 else STREAM) and L.ggq_mmq_route(Q4_K, 4096, k, n) == X64
+        assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if n >= 32 * 191 + 1 else STREAM)
+        assert L.ggq_mmq_route(Q4_K, 128, k, n) == (X64 if n >= 32 * 95 + 1 else STREAM) and L.ggq_mmq_route(Q4_K, 4096, k, n) == X64
         mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows ...
-        big = lambda b: X64 if units64(b, n) >= 160 else None   # ... and from 33 tokens the 64 x 64 wave tiles where the launch has 160 units
+        big = lambda b: X64 if (units64(b, n) >= 160 or units32(b, n) >= 64) else None   # ... and from 33 tokens the x64 kernel (32-row units from 64 of them)
         assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == (big(64) or mid8)
         assert L.ggq_mmq_route(Q8_0, 65, k, n) == (big(65) or STREAM)
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
@@ -144,10 +147,46 @@ def test_mmq_routing_table():
                 assert L.ggq_mmq_stream_unit_tokens(int(t), b, n) == want, (t, b, n)
 
 
+def test_route_regret_with_32_row_units():
+    """profiles/r04b_x64_unit_rows32_*.txt: the streamed kernel, the x64 kernel with 64-row units and with 32-row units (both forced on a
+    tuning build), eleven shapes x six batches per format, op us cold.  What ggq_mmq_route + ggq_mmq_x64_unit_rows pick is within 10 % of
+    the fastest of the three at every point (96-row launches — more than 256 units of 64 — are priced as 64-row here: they only get faster)."""
+    import re
+    from ggq import lib as ggqlib
+    L = ggqlib.cpu()
+    STREAM, X64 = 3, 5
+    for name, t in (("q4_k", 12), ("q8_0", 8), ("q4_0", 2)):
+        cur, data = None, {}
+        for line in open(os.path.join(ROOT, "profiles", f"r04b_x64_unit_rows32_{name}.txt")):
+            m = re.match(r"== type (\d+) unit rows (\d+)", line)
+            if m:
+                cur = int(m.group(2))
+                continue
+            m = re.match(r"\s*(\d+) x\s*(\d+) batch\s*(\d+): route 3\s+([\d.]+) /\s*([\d.]+) \|\s*([\d.]+) /\s*([\d.]+)", line)
+            if m:
+                key = (int(m.group(1)), int(m.group(2)), int(m.group(3)))
+                data.setdefault(key, {})[cur] = (float(m.group(5)), float(m.group(7)))
+        pts = 0
+        for (n, k, b), d in data.items():
+            if 32 not in d or 64 not in d:
+                continue
+            stream, x64, x32 = min(d[64][0], d[32][0]), d[64][1], d[32][1]   # (the streamed kernel was timed in both passes)
+            r = L.ggq_mmq_route(t, b, k, n)
+            if r not in (STREAM, X64):   # Q8_0 batch 33 - 64 on many rows below the x64 thresholds: the LDS-tile kernel
+                assert t == 8 and b <= 64, (n, k, b, r)
+                continue
+            rows = L.ggq_mmq_x64_unit_rows(t, b, k, n)
+            chosen = stream if r == STREAM else (x32 if rows == 32 else x64)
+            best = min(stream, x64, x32)
+            assert chosen <= 1.10 * best, f"{name}: {n} x {k} batch {b}: route {r} / {rows}-row units takes {chosen} us, best {best}"
+            pts += 1
+        assert pts >= 60, (name, pts)
+
+
 def test_x64_launch_shape_rules():
     """K-slices and rows per unit of the 64 x 64 wave-tile kernel (ggq_mmq_x64_k_slices / ggq_mmq_x64_unit_rows): eight slices while a
-    unit has a CU to itself; 96-row units (Q4_K) exactly where 64-row units would need a second workgroup on some CUs and 96-row
-    units do not"""
+    unit has a CU to itself; 96-row units exactly where 64-row units would need a second workgroup on some CUs and 96-row units do
+    not; 32-row units (every wave a one-row-tile wave) below 160 units of 64 rows"""
     from ggq import lib as ggqlib
     L = ggqlib.cpu()
     Q4_K, Q8_0 = 12, 8
@@ -155,12 +194,14 @@ def test_x64_launch_shape_rules():
     assert L.ggq_mmq_x64_k_slices(64, 1024, 4096) == 4                          # fewer than eight super-blocks
     for b, k, n, want in ((128, 4096, 11008, 96), (128, 4096, 8192, 64), (128, 4096, 8193, 96), (128, 4096, 12288, 96), (128, 4096, 12289, 64),
                           (64, 4096, 11008, 64), (256, 4096, 4100, 96), (256, 4096, 6145, 64), (2048, 1024, 600, 96), (128, 768, 11008, 64),
-                          (128, 4096, 28672, 64), (65, 1024, 8230, 96)):
+                          (128, 4096, 28672, 64), (65, 1024, 8230, 96), (128, 4096, 4096, 32), (64, 4096, 8192, 32), (64, 4096, 10176, 32),
+                          (64, 4096, 10177, 64), (128, 4096, 5120, 64), (128, 4096, 5056, 32), (33, 256, 64, 32)):
         assert L.ggq_mmq_x64_unit_rows(Q4_K, b, k, n) == want, (b, k, n)
         assert L.ggq_mmq_x64_unit_rows(Q8_0, b, k, n) == want and L.ggq_mmq_x64_unit_rows(14, b, k, n) == 64   # (Q6_K: not an x64 format)
+        tt = -(-b // 64)
         if want == 96:
-            tt = -(-b // 64)
             assert -(-n // 64) * tt > 256 >= -(-n // 96) * tt
+        assert (want == 32) == (-(-n // 64) * tt < 160)   # 32-row units: fewer than 160 units of 64 rows
 
 
 def test_shipped_code_objects_keep_the_mfma_wait_states():
@@ -247,8 +288,10 @@ def test_route_regret_on_the_committed_sweep():
             if r not in (STREAM, X64):   # Q8_0 batch 33 - 64 on many rows: the LDS-tile kernel (its own audit: profiles/r03_route_audit.txt)
                 assert t == 8 and b <= 64, (n, k, b, r)
                 continue
+            if r == X64 and L.ggq_mmq_x64_unit_rows(t, b, k, n) == 32:
+                continue   # 32-row units: not what these files timed (test_route_regret_with_32_row_units)
             chosen = x64_cold if r == X64 else stream_cold
             regret = chosen / min(stream_cold, x64_cold) - 1.0
             assert regret <= 0.10, f"{fname}: {n} x {k} batch {b}: route {r} takes {chosen} us, the other kernel {min(stream_cold, x64_cold)} us"
             pts += 1
-        assert pts >= 85, (fname, pts)
+        assert pts >= 60, (fname, pts)

@@ -76,7 +76,7 @@ def test_mmq_x64_96_row_units(oracle, t, dtype, batch, k, n_rows):
     util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 96-row units b={batch}")
     if k < 2048:   # (four K-slices whatever the unit count)
         sub = 200
-        assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, sub) == 64
+        assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, sub) in (32, 64)   # (32-row units below 160 units of 64 rows)
         ys = util.gpu_mmq_x64(np.ascontiguousarray(w[:sub]), x, t, sub)
         assert torch.equal(ys, y[:, :sub].contiguous()), "a row's result depends on the unit shape"
     else:          # a taller matrix with the same rows first: 64-row units, four K-slices (more than 256 units)
@@ -85,6 +85,27 @@ def test_mmq_x64_96_row_units(oracle, t, dtype, batch, k, n_rows):
         yb = util.gpu_mmq_x64(np.concatenate([w, w[: big - n_rows]]), x, t, big)
         assert torch.equal(yb[:, :n_rows].contiguous(), y), "a row's result depends on the unit shape"
     assert torch.equal(y, util.gpu_mmq_x64(w, x, t, n_rows)), "two launches differ"
+
+
+@pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("dtype,batch,k,n_rows", [(torch.float16, 128, 1024, 4100), (torch.float32, 70, 768, 2500), (torch.bfloat16, 200, 4096, 1030)])
+def test_mmq_x64_32_row_units(oracle, t, dtype, batch, k, n_rows):
+    """launches below 160 units of 64 rows take 32-row units (every wave a one-row-tile wave; four K-slices, eight at K = 4096): against
+    the oracle (ragged last units of 4 / 4 / 6 rows), and — at four K-slices — bit-equal to the 64-row-unit launch of a taller matrix
+    that starts with the same rows"""
+    L = ggqlib.hip()
+    assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, n_rows) == 32
+    w = synth.random_weight(t, n_rows, k, seed=batch + k + 1)
+    x = _x((batch, k), dtype, seed=19)
+    y = util.gpu_mmq_x64(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 32-row units b={batch}")
+    assert torch.equal(y, util.gpu_mmq_x64(w, x, t, n_rows)), "two launches differ"
+    if k < 2048:
+        big = 4 * n_rows
+        assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, big) == 64 and L.ggq_mmq_x64_k_slices(batch, k, big) == 4
+        yb = util.gpu_mmq_x64(np.concatenate([w] * 4), x, t, big)
+        assert torch.equal(yb[:, :n_rows].contiguous(), y), "a row's result depends on the unit shape"
 
 
 @pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
