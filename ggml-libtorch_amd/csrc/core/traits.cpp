@@ -101,7 +101,7 @@ extern "C" size_t ggq_mmq_scratch_bytes(int64_t batch, int64_t k) {
 // the 64 x 64 wave-tile kernel (csrc/hip/mmq_x64.hip)
 extern "C" int ggq_mmq_x64_type_supported(int type) {
   switch (type) {
-    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q4_0: return 1;
+    case GGQ_TYPE_Q4_K: case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q5_K: return 1;
     default: return 0;
   }
 }
@@ -119,6 +119,7 @@ extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
 // 168 units on for all three, where 64- / 96-row units stay.  Bit-identical to the other unit shapes (same loops, same slice order).
 extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows) {
   if (!ggq_mmq_x64_type_supported(type)) return 64;
+  if (type == GGQ_TYPE_Q5_K) return 32;   // its 176-byte super-blocks fit the LDS as 32-row stages only (mmq_x64.hip, X64Fmt)
   const int64_t tt = (batch + 63) / 64;
   const int64_t u64 = ((n_rows + 63) / 64) * tt, u96 = ((n_rows + 95) / 96) * tt;
   if (u64 < 160) return 32;
@@ -128,6 +129,7 @@ extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t
 static int64_t x64_min_units32(int type) {
   switch (type) {
     case GGQ_TYPE_Q4_K: return 192;
+    case GGQ_TYPE_Q5_K: return 128;   // (32-row units only, profiles/r04b_x64_vs_stream_q5_k.txt: 1.01 - 1.26 x the streamed kernel cold from 128 units of 32)
     case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q4_0: return 64;
     default: return 0;
   }

@@ -81,6 +81,13 @@ template <int KS> struct X64Lds { static constexpr int BYTES = KS * X64_WAVE_LDS
 constexpr int X64_STAGE_R1 = 32 * 144;
 constexpr int X64_WAVE_LDS_R1 = 2 * X64_STAGE_R1 + 2048;
 constexpr int X64_LDS_R3 = 4 * X64_WAVE_LDS + 4 * X64_WAVE_LDS_R1;
+// Q5_K: 176-byte super-blocks at a 176-byte pitch (11 chunks), one-row-tile waves only (two stages of 64 rows would be 196 KB for eight waves)
+template <int T> struct X64Fmt {
+  static constexpr int PITCH = T == GGQ_TYPE_Q5_K ? 176 : 144;      // LDS bytes per row of a stage
+  static constexpr int CPR = PITCH / 16, RPI = 63 / CPR;            // 16-byte chunks per row; rows one DMA instruction covers
+  static constexpr int STAGE_R1 = 32 * PITCH, WAVE_LDS_R1 = 2 * STAGE_R1 + 2048;
+  static constexpr bool ONLY_32 = T == GGQ_TYPE_Q5_K;
+};
 
 // UR = weight rows per unit: 64; 96 (R3, above); 32 (U32: every wave a one-row-tile wave — the form for launches with too few 64-row
 // units to fill the chip: twice the units, half the work each; ggq_mmq_x64_unit_rows)
@@ -91,6 +98,7 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
                                                          const void* __restrict__ aux, GatherOut go) {
   constexpr bool R3 = UR == 96, U32 = UR == 32;
   static_assert(UR == 32 || UR == 64 || UR == 96, "unit rows");
+  static_assert(UR == 32 || !X64Fmt<T>::ONLY_32, "this format has the one-row-tile loop only");
   static_assert(!R3 || KS == 4, "96-row units: four K-slices");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
@@ -133,12 +141,13 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
     const uint32_t n_tt32 = 2u * (uint32_t)n_tok_tiles;                  // 32-token records per super-block
     const uint32_t sbstride = n_tt32 * X64_REC;
     const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
-    const uint32_t ring = (uint32_t)(uintptr_t)lds + (U32 ? (uint32_t)ks * X64_WAVE_LDS_R1
+    using XF = X64Fmt<T>;
+    const uint32_t ring = (uint32_t)(uintptr_t)lds + (U32 ? (uint32_t)ks * XF::WAVE_LDS_R1
                                                            : one_tile ? 4u * X64_WAVE_LDS + (uint32_t)ks * X64_WAVE_LDS_R1 : (uint32_t)ks * X64_WAVE_LDS);
     // LDS-DMA source offset of this lane inside the seven rows one instruction copies: row lane / 9, 16-byte chunk lane % 9
     // (lane 63 = chunk 0 of the next instruction's first row: both write the same bytes)
-    const uint32_t dmaoff = (uint32_t)(lane / 9) * row_bytes + (uint32_t)(lane % 9) * 16u;
-    const uint32_t ldsd = ring + 2 * (one_tile ? X64_STAGE_R1 : X64_STAGE) + (uint32_t)h * 64u;
+    const uint32_t dmaoff = (uint32_t)(lane / XF::CPR) * row_bytes + (uint32_t)(lane % XF::CPR) * 16u;
+    const uint32_t ldsd = ring + 2 * (one_tile ? XF::STAGE_R1 : X64_STAGE) + (uint32_t)h * 64u;
     const uint32_t nsb = (uint32_t)(sb_end - sb_begin);
     X64_STAMP(1);
     if constexpr (T == GGQ_TYPE_Q8_0) {   // 272 bytes of a row per 256 elements, in two 128-element stages at a 144-byte LDS pitch
@@ -149,6 +158,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
       else
       x64_loop_q80(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                    sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+    } else if constexpr (T == GGQ_TYPE_Q5_K) {   // one-row-tile waves only; header 16 bytes, qh 32, quants from byte 48
+      const uint32_t hoff = 48u + 16u * (uint32_t)h;
+      x64_loop_q5k_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 176u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                      sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else if constexpr (T == GGQ_TYPE_Q4_0) {   // 144 bytes of a row per 256 elements (eight 18-byte blocks): one stage; both lane halves read the same bytes
       const uint32_t hoff = 16u * (uint32_t)h;
       if (one_tile)
@@ -289,7 +302,7 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
 template <int T, int DT, int KS, int UR>
 static int launch_x64_inst(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
                            const X64Epilogue& ep, int64_t n_tok_tiles, int64_t n_units) {
-  constexpr int LDS = UR == 96 ? X64_LDS_R3 : UR == 32 ? KS * X64_WAVE_LDS_R1 : X64Lds<KS>::BYTES;
+  constexpr int LDS = UR == 96 ? X64_LDS_R3 : UR == 32 ? KS * X64Fmt<T>::WAVE_LDS_R1 : X64Lds<KS>::BYTES;
   constexpr int NTHR = UR == 96 ? 512 : 64 * KS;
   const int64_t per_xcd = (n_units + 7) / 8;
   auto kern = mmq_x64_kernel<T, DT, KS, UR>;
@@ -312,15 +325,21 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
                                                                              : ggq_mmq_x64_unit_rows(T, batch, k, n);
   const int64_t n_units = ((n + unit_rows - 1) / unit_rows) * n_tok_tiles;
   if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
-  if (unit_rows == 96) return launch_x64_inst<T, DT, 4, 96>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
+  if constexpr (X64Fmt<T>::ONLY_32) {
+    if (unit_rows != 32) return GGQ_ERR_SHAPE;   // (ggq_mmq_x64_unit_rows returns 32 for these formats; a tuning override must too)
+  } else {
+    if (unit_rows == 96) return launch_x64_inst<T, DT, 4, 96>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
+  }
   // at most one unit per CU: eight K-slices per unit (two waves per SIMD either way, half the K loop per wave); otherwise four, two
   // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable; for 32-row units the same rule on their count)
   const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : (n_units <= 256 && k >= 8 * 256 ? 8 : 4);
   if (unit_rows == 32)
     return ks == 8 ? launch_x64_inst<T, DT, 8, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
                    : launch_x64_inst<T, DT, 4, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
-  return ks == 8 && k >= 8 * 256 ? launch_x64_inst<T, DT, 8, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
-                                 : launch_x64_inst<T, DT, 4, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
+  if constexpr (!X64Fmt<T>::ONLY_32)
+    return ks == 8 && k >= 8 * 256 ? launch_x64_inst<T, DT, 8, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
+                                   : launch_x64_inst<T, DT, 4, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
+  return GGQ_ERR_SHAPE;
 }
 
 template <int T>
@@ -364,6 +383,7 @@ int ggq::mul_mat_q_x64_impl(const void* w, const void* q, void* y, int type, int
     case GGQ_TYPE_Q4_K: return launch_x64_dt<GGQ_TYPE_Q4_K>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     case GGQ_TYPE_Q8_0: return launch_x64_dt<GGQ_TYPE_Q8_0>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     case GGQ_TYPE_Q4_0: return launch_x64_dt<GGQ_TYPE_Q4_0>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
+    case GGQ_TYPE_Q5_K: return launch_x64_dt<GGQ_TYPE_Q5_K>(w, q, y, dtype, batch, k, n_rows, ldy, (hipStream_t)stream, ep);
     default: return GGQ_ERR_TYPE;
   }
 }

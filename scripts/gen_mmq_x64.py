@@ -124,6 +124,23 @@ class Q4K:
     QS_OFF = 16              # first quant byte inside the super-block
     STAGE = ROWS * 144
     ROWS = ROWS
+    RPI = 7                  # rows one DMA instruction covers (63 // CPR)
+    Q5 = False
+
+
+class Q5K_R1:
+    """Q5_K, one-row-tile waves only (32 rows x 64 tokens): 176-byte super-blocks {d, dmin, scales[12]; qh[32]; qs[128]} at a 176-byte pitch
+    (11 chunks: odd, conflict-free) — two stages of 64 rows would not fit eight waves' LDS, two of 32 rows do (13 KB per wave).  Q4_K's
+    header, scales and min term as they are; the operand is the nibble | bit g of qh[l] << 4: the lane's 16 qh bytes are read once per
+    super-block (the next one's beside the next header) and cost two more vector instructions per operand register."""
+    name, type_id = "q5k", 13
+    BS = 176
+    CPR, RPI = 11, 5
+    ROWS = 32
+    N_DMA = 7                # 6 x 5 rows + 2
+    QS_OFF = 48
+    STAGE = 32 * 176
+    Q5 = True
 
 
 class Q4K_R1(Q4K):
@@ -140,6 +157,7 @@ class Q80:
     which two ALIGNED ds_read_b128 cover; v_alignbyte_b32 / v_mov_b32 move them into place (a misaligned ds_read_b128 costs 3.4 x)."""
     name, type_id = "q80", 8
     BS = 136
+    RPI = 7
     CPR, DIV = 9, 7282
     N_DMA = 10
     STAGE = ROWS * 144
@@ -160,6 +178,7 @@ class Q40:
     constants x = 0x08 / 0x80 and s = 4 / 0; the row scale is d / 16."""
     name, type_id = "q40", 2
     BS = 144
+    RPI = 7
     CPR, DIV = 9, 7282
     N_DMA = 10
     STAGE = ROWS * 144
@@ -231,15 +250,42 @@ def dw_prep(a, q, rt):
         a.i(f"v_pk_mul_f32 {vr(DWNM[rt] + 4 * par + 2, 2)}, {vr(DWNM[rt] + 4 * par, 2)}, {sr(S_NEGM, 2)}")
 
 
-def w_hi(a, rt):
+QH, QHN = 200, 204           # Q5_K (one-row-tile loop: the second row tile's header registers are free): the lane's 16 qh bytes, this / next super-block
+S_MASK10 = 65
+
+
+def q5_hi(a, rt, g):
+    """Q5_K: operand of group g = (bit g of the qh bytes << 4) | nibble (in T_WHI)"""
+    a.wait_lg("qh")
+    sh = 4 - (g & 7)
+    src = QH
+    if sh:
+        for k in range(4):
+            a.i(f"v_lsh{'l' if sh > 0 else 'r'}rev_b32 {vr(T_DW + k)}, {abs(sh)}, {vr(QH + k)}")
+        src = T_DW
+    for k in range(4):
+        a.i(f"v_and_or_b32 {vr(WOP[rt] + k)}, {vr(src + k)}, {sr(S_MASK10)}, {vr(T_WHI + k)}")
+
+
+def w_hi(a, rt, g=None):
     for k in range(4):
         a.i(f"v_lshrrev_b32 {vr(T_WHI + k)}, 4, {vr(RAW[rt] + k)}")
+    if F.Q5:
+        for k in range(4):
+            a.i(f"v_and_b32 {vr(T_WHI + k)}, {sr(S_MASK0F)}, {vr(T_WHI + k)}")
+        q5_hi(a, rt, g)
+        return
     for k in range(4):
         a.i(f"v_and_b32 {vr(WOP[rt] + k)}, {sr(S_MASK0F)}, {vr(T_WHI + k)}")
 
 
-def w_lo(a, rt):
+def w_lo(a, rt, g=None):
     a.wait_lg(f"raw{rt}")
+    if F.Q5:
+        for k in range(4):
+            a.i(f"v_and_b32 {vr(T_WHI + k)}, {sr(S_MASK0F)}, {vr(RAW[rt] + k)}")
+        q5_hi(a, rt, g)
+        return
     for k in range(4):
         a.i(f"v_and_b32 {vr(WOP[rt] + k)}, {sr(S_MASK0F)}, {vr(RAW[rt] + k)}")
 
@@ -302,10 +348,10 @@ def dma_instr(a, j, dst_stage):
         a.i(f"s_mov_b32 {sr(S_T1)}, {sr(S_WKN)}")
     else:
         a.i(f"s_add_u32 {sr(S_T1)}, {sr(S_T1)}, {sr(S_RB7)}")
-    a.i(f"s_add_u32 m0, {sr(dst_stage)}, {16 * 7 * F.CPR * j}")
+    a.i(f"s_add_u32 m0, {sr(dst_stage)}, {16 * F.RPI * F.CPR * j}")
     if j == F.N_DMA - 1:
         a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
-        mask = (1 << (F.CPR * (F.ROWS - 7 * j))) - 1
+        mask = (1 << (F.CPR * (F.ROWS - F.RPI * j))) - 1
         if mask < (1 << 32):
             a.i(f"s_mov_b64 exec, {hex(mask)}")
         else:
@@ -551,20 +597,22 @@ def gen(label):
 
 
 
-def gen_r1(label):
+def gen_r1(label, fmt=None):
     """Q4_K, ONE row tile per wave (32 rows x 64 tokens, tiles ti = 0, 2 = token tiles 0, 1; accumulators v[0:15], v[32:47]): the
     second wave kind of the 96-row units.  Same pipeline as gen() with two slots per group: slot (g, 0) carries the loads (activations,
     weight DMA), slot (g, 2) the unpack / scale work of the one row tile (its operand is free once MFMA(g, 2) has issued)."""
     global F, R1
-    F, R1 = Q4K_R1, True
+    fmt = fmt or Q4K_R1
+    F, R1 = fmt, True
     a = Asm()
     for s in (S_NEGM, S_NEGM + 1):
         a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
     for s in (S_256, S_256 + 1):
         a.i(f"s_mov_b32 {sr(s)}, 0x43800000")
     a.i(f"s_mov_b32 {sr(S_MASK0F)}, 0x0f0f0f0f")
+    a.i(f"s_mov_b32 {sr(S_MASK10)}, 0x10101010")
     a.i(f"s_mov_b32 {sr(S_1024)}, 0x44800000")
-    a.i(f"v_cmp_ne_u32_e64 {sr(S_HI, 2)}, 16, {vr(V_HOFF)}")
+    a.i(f"v_cmp_ne_u32_e64 {sr(S_HI, 2)}, {F.QS_OFF}, {vr(V_HOFF)}")      # lanes 32-63 (hoff = QS_OFF + 16 h)
     a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_LDS)}")
     a.i(f"s_add_u32 {sr(S_NSTAGE)}, {sr(S_LDS)}, {F.STAGE}")
     a.i(f"s_mov_b32 {sr(S_WKN)}, {sr(S_WK)}")
@@ -592,9 +640,12 @@ def gen_r1(label):
     a.wait_vm("dma")
     a.wait_vm("d8dma0_1")
     hdr_read(a, 0)
+    if F.Q5:
+        a.i(f"v_subrev_u32 {vr(T_HD)}, 32, {vr(V_LDSW)}")         # the lane's qh bytes: QS_OFF - 32 + 16 h into the row
+        a.lds(f"ds_read_b128 {vr(QH, 4)}, {vr(T_HD)}", "qh")
     a.lds(f"ds_read_b128 {vr(RAW[0], 4)}, {vr(V_LDSW)} offset:0", "raw0")
     hdr_decode(a, 0)
-    w_lo(a, 0)
+    w_lo(a, 0, 0)
     d8_reads(a, 0, 0)
     a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
     Asm.armed = True
@@ -638,15 +689,22 @@ def gen_r1(label):
         if g == 6:
             a.wait_vm("dma")
         if g % 2 == 0:
-            w_hi(a, 0)
+            w_hi(a, 0, g + 1)
             raw_read(a, 0, q + 1)
             dw_prep(a, q, 0)                     # row scales of groups g, g + 1 (the odd group's old ones were last read in slot (g, 0))
         else:
-            w_lo(a, 0)
+            if g == 7 and F.Q5:                  # the next super-block's qh bytes (read in slot (6, 2); group 7's operand is built)
+                a.wait_lg("qh")
+                for k in range(4):
+                    a.i(f"v_mov_b32 {vr(QH + k)}, {vr(QHN + k)}")
+            w_lo(a, 0, g + 1)
         if g == 3:
             d8_dma(a, 1, 0, True)
         if g == 6:
             hdr_read(a, 0)
+            if F.Q5:
+                a.i(f"v_subrev_u32 {vr(T_HD)}, 32, {vr(V_LDSWN)}")
+                a.lds(f"ds_read_b128 {vr(QHN, 4)}, {vr(T_HD)}", "qh")
         if g == 7:
             hdr_decode(a, 0)
             d8_dma(a, 0, 1, True)                # groups 4-7 of the next super-block (this one's group 7 was read in slots (6, 2) / (7, 0))
@@ -1177,7 +1235,7 @@ def emit(a, fn_name):
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
     clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
     s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1,
-             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
+             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_MASK10, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
     clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
     return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
 static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,
@@ -1200,6 +1258,7 @@ if __name__ == "__main__":
     a = gen("q4k")
     b = gen_q80("q80")
     c = gen_r1("r1_q4k_")
+    g5 = gen_r1("r1_q5k_", Q5K_R1)
     d = gen_q80_r1("r1_q80_")
     e4 = gen_q40("q40_")
     f4 = gen_q40_r1("r1_q40_")
@@ -1212,4 +1271,5 @@ if __name__ == "__main__":
         f.write(emit(d, "x64_loop_q80_r1"))
         f.write(emit(e4, "x64_loop_q40"))
         f.write(emit(f4, "x64_loop_q40_r1"))
+        f.write(emit(g5, "x64_loop_q5k_r1"))
     print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)

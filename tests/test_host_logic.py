@@ -74,7 +74,7 @@ def test_mmq_routing_table():
                 assert r in (DOT4, LDS_TILE, STREAM, T16, X64)
                 # the 64 x 64 wave tiles: from 33 tokens, where the launch has at least 160 units of 64 rows — or, with the kernel's 32-row
                 # units, at least 192 (Q4_K) / 64 (Q8_0, Q4_0) units of 32 rows — for the formats the kernel serves
-                big_enough = units64(b, n) >= 160 or units32(b, n) >= {Q4_K: 192, Q8_0: 64, Q4_0: 64}.get(int(t), 1 << 62)
+                big_enough = units64(b, n) >= 160 or units32(b, n) >= {Q4_K: 192, Q5_K: 128, Q8_0: 64, Q4_0: 64}.get(int(t), 1 << 62)
                 if r == X64:
                     assert b >= 33 and k % 256 == 0 and big_enough and L.ggq_mmq_x64_supported(int(t), k, b) == 1
                 elif b >= 33 and k % 256 == 0 and big_enough:
@@ -276,7 +276,7 @@ def test_route_regret_on_the_committed_sweep():
     L = ggqlib.cpu()
     STREAM, X64 = 3, 5
     for fname, t in (("r04_x64_vs_stream_q4k_ks4.txt", 12), ("r04b_x64_vs_stream_q4_k.txt", 12), ("r04b_x64_vs_stream_q8_0.txt", 8),
-                     ("r04b_x64_vs_stream_q4_0.txt", 2)):   # (r04b: re-measured with the 96-row units, the streamed kernel forced on the other side)
+                     ("r04b_x64_vs_stream_q4_0.txt", 2), ("r04b_x64_vs_stream_q5_k.txt", 13)):   # (r04b: the final kernels, the streamed kernel forced on the other side)
         pts = 0
         for line in open(os.path.join(ROOT, "profiles", fname)):
             m = re.match(r"\s*(\d+) x\s*(\d+) batch\s*(\d+): route 3\s+([\d.]+) /\s*([\d.]+) \|\s*([\d.]+) /\s*([\d.]+)", line)
@@ -288,8 +288,8 @@ def test_route_regret_on_the_committed_sweep():
             if r not in (STREAM, X64):   # Q8_0 batch 33 - 64 on many rows: the LDS-tile kernel (its own audit: profiles/r03_route_audit.txt)
                 assert t == 8 and b <= 64, (n, k, b, r)
                 continue
-            if r == X64 and L.ggq_mmq_x64_unit_rows(t, b, k, n) == 32:
-                continue   # 32-row units: not what these files timed (test_route_regret_with_32_row_units)
+            if r == X64 and t != 13 and L.ggq_mmq_x64_unit_rows(t, b, k, n) == 32:
+                continue   # 32-row units: not what these files timed (test_route_regret_with_32_row_units); Q5_K has no other units
             chosen = x64_cold if r == X64 else stream_cold
             regret = chosen / min(stream_cold, x64_cold) - 1.0
             assert regret <= 0.10, f"{fname}: {n} x {k} batch {b}: route {r} takes {chosen} us, the other kernel {min(stream_cold, x64_cold)} us"

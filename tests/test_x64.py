@@ -20,6 +20,10 @@ X64_TYPES = [t for t in (GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q4_0, GGMLType.Q
              if ggqlib.hip().ggq_mmq_x64_type_supported(int(t))] if torch.cuda.is_available() else []
 
 
+# formats with 64- and 96-row units (Q5_K has the one-row-tile loop only: 32-row units at every size)
+X64_TYPES_64 = [t for t in X64_TYPES if ggqlib.hip().ggq_mmq_x64_unit_rows(int(t), 128, 4096, 11008) == 96] if torch.cuda.is_available() else []
+
+
 def _x(shape, dtype, seed=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randn(shape, generator=g).to(dtype).cuda()
@@ -51,7 +55,7 @@ def test_mmq_x64_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 mmq {t.name} b={batch}")
 
 
-@pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("t", X64_TYPES_64, ids=lambda t: t.name)
 @pytest.mark.parametrize("dtype,batch,k,n_rows", [(torch.float16, 128, 1024, 8230), (torch.float32, 100, 1280, 8257), (torch.bfloat16, 256, 1024, 4100),
                                                   (torch.float16, 2048, 1024, 600), (torch.float16, 128, 4096, 8200)])
 def test_mmq_x64_96_row_units(oracle, t, dtype, batch, k, n_rows):
@@ -96,12 +100,21 @@ def test_mmq_x64_32_row_units(oracle, t, dtype, batch, k, n_rows):
     L = ggqlib.hip()
     assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, n_rows) == 32
     w = synth.random_weight(t, n_rows, k, seed=batch + k + 1)
+    from ggq.synth import _F16_FIELDS
+    bs, m_off = BLOCK[t][1], _F16_FIELDS[t][1]
+    if m_off is not None and dtype != torch.float16:   # every seventh row: dmin over the whole range incl. the 2^-8-scaled cold pass
+        wb = w.reshape(n_rows, -1, bs)
+        vals = np.array([6e-8, 1.0, 1023.5, 1024.5, 65504.0, -65504.0, -3.0, 0.0, -2000.0], np.float16)
+        for r in range(0, n_rows, 7):
+            for b in range(wb.shape[1]):
+                wb[r, b, m_off:m_off + 2] = vals[(r + 5 * b) % len(vals)].reshape(1).view(np.uint8)
+        w = wb.reshape(n_rows, -1)
     x = _x((batch, k), dtype, seed=19)
     y = util.gpu_mmq_x64(w, x, t, n_rows)
     ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
     util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 32-row units b={batch}")
     assert torch.equal(y, util.gpu_mmq_x64(w, x, t, n_rows)), "two launches differ"
-    if k < 2048:
+    if k < 2048 and t in X64_TYPES_64:
         big = 4 * n_rows
         assert L.ggq_mmq_x64_unit_rows(int(t), batch, k, big) == 64 and L.ggq_mmq_x64_k_slices(batch, k, big) == 4
         yb = util.gpu_mmq_x64(np.concatenate([w] * 4), x, t, big)
@@ -222,7 +235,10 @@ def test_mmq_x64_reference_benchmark_batch(oracle, t):
     x = _x((batch, k), torch.float16, seed=32)
     y = util.gpu_mmq_x64(w, x, t, n_rows)
     y128 = util.gpu_mmq_x64(w, x[:128].contiguous(), t, n_rows)
-    assert torch.equal(y[:128], y128)
+    if t in X64_TYPES_64:
+        assert torch.equal(y[:128], y128)
+    else:   # Q5_K: 32-row units at both sizes, but 512 of them take four K-slices and 32 take eight: same sum, another order (include/ggq.h)
+        assert torch.allclose(y[:128].float(), y128.float(), rtol=2e-3, atol=2e-2)
     rows = np.arange(0, n_rows, 16)
     toks = np.arange(0, batch, 37)
     ref, yabs = oracle.mul_mat_q(np.ascontiguousarray(w[rows]), x.float().cpu().numpy()[toks], t, len(rows))
