@@ -211,7 +211,7 @@ int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch);
 /* K-slices (= waves) per 64 x 64 unit the x64 kernel uses for a shape: 8 while there is at most one unit per CU, else 4 (32-row units: the
  * same rule on their count; 96-row units: always 4).  Host-only. */
 int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows);
-/* Weight rows per unit: 32 below 160 units of 64 rows, else 64, or 96 where that makes the launch one even round of at most 256
+/* Weight rows per unit: 32 below 160 units of 64 rows (Q5_K: always), else 64, or 96 where that makes the launch one even round of at most 256
  * workgroups.  A row's bits do not depend on it (at equal K-slice count).  Host-only. */
 int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows);
 int ggq_quantize_q8_1_x64(const void* x, int x_dtype, void* q, int64_t batch, int64_t k, int type, void* stream);
