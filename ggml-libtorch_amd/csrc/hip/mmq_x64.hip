@@ -87,11 +87,13 @@ template <int T> struct X64Fmt {
   static constexpr int CPR = PITCH / 16, RPI = 63 / CPR;            // 16-byte chunks per row; rows one DMA instruction covers
   static constexpr int STAGE_R1 = 32 * PITCH, WAVE_LDS_R1 = 2 * STAGE_R1 + 2048;
   static constexpr bool ONLY_32 = T == GGQ_TYPE_Q5_K;
+  static constexpr bool HAS_T1 = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;   // a one-tile loop (32 rows x 32 tokens per wave) exists
 };
 
 // UR = weight rows per unit: 64; 96 (R3, above); 32 (U32: every wave a one-row-tile wave — the form for launches with too few 64-row
 // units to fill the chip: twice the units, half the work each; ggq_mmq_x64_unit_rows)
-template <int T, int DT, int KS, int UR>
+// TT = token tiles of 32 per wave: 2; 1 with 32-row units for batches up to 32 tokens (the one-tile loops: no padding to 64 tokens)
+template <int T, int DT, int KS, int UR, int TT = 2>
 __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mmq_x64_kernel(const uint8_t* __restrict__ w, const uint8_t* __restrict__ q8,
                                                          void* __restrict__ y, int k, int n_rows, int batch, int64_t ldy,
                                                          int n_tok_tiles, int n_units, int per_xcd, int epi,
@@ -100,12 +102,13 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
   static_assert(UR == 32 || UR == 64 || UR == 96, "unit rows");
   static_assert(UR == 32 || !X64Fmt<T>::ONLY_32, "this format has the one-row-tile loop only");
   static_assert(!R3 || KS == 4, "96-row units: four K-slices");
+  static_assert(TT == 2 || (TT == 1 && U32 && X64Fmt<T>::HAS_T1), "one token tile: 32-row units, formats with a one-tile loop");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
   if (unit >= n_units) return;
   constexpr int UROWS = UR;
   const int row_tile = unit / n_tok_tiles, tok_tile = unit % n_tok_tiles;
-  const int t0 = tok_tile * 64;
+  const int t0 = tok_tile * (32 * TT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool one_tile = U32 || (R3 && wave >= 4);         // the wave kind with one row tile (R3: rows 64-95 of the unit)
@@ -138,9 +141,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(w + (int64_t)nb * row_bytes), 0, (int)((uint32_t)valid_rows * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q8, 0, (int)0xFFFFFFFFu, 0x00020000);
-    const uint32_t n_tt32 = 2u * (uint32_t)n_tok_tiles;                  // 32-token records per super-block
+    // 32-token records per super-block (the scratch layout pads the batch to a multiple of 64 tokens)
+    const uint32_t n_tt32 = TT == 2 ? 2u * (uint32_t)n_tok_tiles : 2u * (uint32_t)((batch + 63) / 64);
     const uint32_t sbstride = n_tt32 * X64_REC;
-    const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + 2u * (uint32_t)tok_tile) * X64_REC;
+    const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + (uint32_t)TT * (uint32_t)tok_tile) * X64_REC;
     using XF = X64Fmt<T>;
     const uint32_t ring = (uint32_t)(uintptr_t)lds + (U32 ? (uint32_t)ks * XF::WAVE_LDS_R1
                                                            : one_tile ? 4u * X64_WAVE_LDS + (uint32_t)ks * X64_WAVE_LDS_R1 : (uint32_t)ks * X64_WAVE_LDS);
@@ -160,6 +164,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
                    sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else if constexpr (T == GGQ_TYPE_Q5_K) {   // one-row-tile waves only; header 16 bytes, qh 32, quants from byte 48
       const uint32_t hoff = 48u + 16u * (uint32_t)h;
+      if constexpr (TT == 1)
+        x64_loop_q5k_t1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 176u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+      else
       x64_loop_q5k_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 176u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                       sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else if constexpr (T == GGQ_TYPE_Q4_0) {   // 144 bytes of a row per 256 elements (eight 18-byte blocks): one stage; both lane halves read the same bytes
@@ -172,7 +180,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
                      sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
     } else {
       const uint32_t hoff = 16u + 16u * (uint32_t)h;
-      if (one_tile)
+      if constexpr (TT == 1)
+        x64_loop_q4k_t1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+      else if (one_tile)
         x64_loop_q4k_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                         sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
       else
@@ -209,7 +220,7 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
   constexpr int RPT = UROWS * 64 / NTHR;   // rows per thread: 16 (four waves), 8 (eight), 12 (96-row units), 8 / 4 (32-row units)
   const int tl64 = tid / (UROWS / RPT), rb = (tid % (UROWS / RPT)) * RPT;
   const int t = t0 + tl64;
-  if (t < batch) {
+  if (t < batch && (TT == 2 || tl64 < 32)) {
   const int tt = tl64 >> 5, tl = tl64 & 31;
   const int i_reg = 4 * (tl >> 3) + (tl & 3), hh = (tl >> 2) & 1;
   float v[RPT];
@@ -299,13 +310,13 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
   }
 }
 
-template <int T, int DT, int KS, int UR>
+template <int T, int DT, int KS, int UR, int TT = 2>
 static int launch_x64_inst(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
                            const X64Epilogue& ep, int64_t n_tok_tiles, int64_t n_units) {
   constexpr int LDS = UR == 96 ? X64_LDS_R3 : UR == 32 ? KS * X64Fmt<T>::WAVE_LDS_R1 : X64Lds<KS>::BYTES;
   constexpr int NTHR = UR == 96 ? 512 : 64 * KS;
   const int64_t per_xcd = (n_units + 7) / 8;
-  auto kern = mmq_x64_kernel<T, DT, KS, UR>;
+  auto kern = mmq_x64_kernel<T, DT, KS, UR, TT>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return GGQ_ERR_LAUNCH;
   GGQ_HIP_PRE_LAUNCH();
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NTHR), LDS, s, (const uint8_t*)w, (const uint8_t*)q8, y, (int)k, (int)n,
@@ -317,10 +328,19 @@ static int launch_x64_inst(const void* w, const void* q8, void* y, int64_t batch
 template <int T, int DT>
 static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int64_t k, int64_t n, int64_t ldy, hipStream_t s,
                       X64Epilogue ep) {
-  const int64_t n_tok_tiles = (batch + 63) / 64;
   // -DGGQ_TUNING builds only (scripts/sweep_x64.py): GGQ_X64_KS forces 4 or 8 K-slices, GGQ_X64_ROWS 32- / 64- / 96-row units
   static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");
   static const char* er = GGQ_TUNING_ENV("GGQ_X64_ROWS");
+  if constexpr (X64Fmt<T>::HAS_T1) {
+    if (batch <= 32) {   // one 32-token tile: 32-row units of one MFMA tile per wave and group
+      const int64_t n_units = (n + 31) / 32;
+      if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
+      const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : (n_units <= 256 && k >= 8 * 256 ? 8 : 4);
+      return ks == 8 ? launch_x64_inst<T, DT, 8, 32, 1>(w, q8, y, batch, k, n, ldy, s, ep, 1, n_units)
+                     : launch_x64_inst<T, DT, 4, 32, 1>(w, q8, y, batch, k, n, ldy, s, ep, 1, n_units);
+    }
+  }
+  const int64_t n_tok_tiles = (batch + 63) / 64;
   const int unit_rows = er && (er[0] == '3' || er[0] == '6' || er[0] == '9') ? (er[0] == '9' ? 96 : er[0] == '3' ? 32 : 64)
                                                                              : ggq_mmq_x64_unit_rows(T, batch, k, n);
   const int64_t n_units = ((n + unit_rows - 1) / unit_rows) * n_tok_tiles;

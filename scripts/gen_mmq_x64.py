@@ -202,7 +202,12 @@ DREG = ((208, 209), (210, 211))   # Q8_0: the block's fp16 d, [row tile][group p
 S_RUNA, S_RUNB, S_NEXTW = 75, 76, 77   # Q8_0: running source offsets of the two stage copies, byte step to the next 256 elements
 
 
+T1 = False                  # one-tile schedule (gen_t1): one MFMA tile per group, result sets alternate by group
+
+
 def cset(g, ti):
+    if T1:
+        return CSET[g & 1]
     return CSET[(2 * g + (ti >> 1)) & 1] if R1 else CSET[(4 * g + ti) & 1]
 
 
@@ -754,6 +759,184 @@ def gen_r1(label, fmt=None):
     return a
 
 
+V_LDSDT = 214                # one-tile loops: LDS address of the CURRENT super-block's token-scale table (two tables, used alternately)
+S_DTAB = 82                  # ... LDS address of the table the next super-block's scales are copied into
+
+
+def t1_d8_dma(a, nxt):
+    """one-tile loops: all eight groups' token scales of one super-block (1 KB: two 32-lane DMA instructions) into the table S_DTAB points
+    at; the token-tile-1 table of the two-tile loops is the second table here, so a request has a whole iteration of lead"""
+    for half in range(2):
+        a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_D0)}, {512 * half}")
+        if nxt:
+            a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_NEXT)}")
+        a.i(f"s_add_u32 m0, {sr(S_DTAB)}, {512 * half}")
+        a.i(f"s_mov_b64 {sr(S_EXEC, 2)}, exec")
+        a.i("s_mov_b64 exec, 0xffffffff")
+        a.vmem(f"buffer_load_dwordx4 {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_T0)} offen lds", f"d8t{half}")
+        a.i(f"s_mov_b64 exec, {sr(S_EXEC, 2)}")
+
+
+def t1_d8_reads(a, target):
+    if target == 0:
+        a.wait_vm("d8t1")                # this super-block's table: requested at the top of the iteration before (or in the prologue)
+    for k in range(4):
+        a.lds(f"ds_read_b128 {vr(D8[0] + 4 * k, 4)}, {vr(V_LDSDT)} offset:{128 * target + 16 * k}", "d8_0" if k == 3 else "d8_0x")
+
+
+def t1_common_prologue(a):
+    a.i(f"s_add_u32 {sr(S_DTAB)}, {sr(S_LDS)}, {2 * F.STAGE}")
+    a.i(f"v_mov_b32 {vr(V_LDSDT)}, {vr(V_LDSD)}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
+    t1_d8_dma(a, False)                                           # the first super-block's scales -> table 0
+    a.i(f"s_add_u32 {sr(S_DTAB)}, {sr(S_DTAB)}, 1024")             # the next one's go to table 1
+    a.vmem(f"buffer_load_dwordx4 {vr(ACT[0][0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F0)} offen", "act0_0")
+    a.i(f"s_add_u32 {sr(S_F0)}, {sr(S_F0)}, 0x400")
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(CSET[1] + k)}, {vr(MAGICV + k)}")     # the first "previous tile" FMA block, group 7: adds zero
+    for k in range(16):
+        a.i(f"v_mov_b32 {vr(D8[0] + k)}, 0")
+    for k in range(4, 8):
+        a.i(f"v_mov_b32 {vr(DWNM[0] + k)}, 0")
+
+
+def t1_act_load(a, g):
+    """the fragment of group g + 1 (token tile 0 only), then the running offset to group g + 2"""
+    par = (g + 1) & 1
+    a.vmem(f"buffer_load_dwordx4 {vr(ACT[par][0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F0)} offen", f"act0_{par}")
+    a.i(f"s_add_u32 {sr(S_F0)}, {sr(S_F0)}, {sr(S_INC6) if g == 6 else '0x400'}")
+
+
+def gen_t1(label, fmt=None):
+    """Q4_K / Q5_K, ONE MFMA tile per wave and group (32 rows x 32 tokens; accumulators v[0:15]): batches of 17 - 32 tokens.  One slot per
+    group: MFMA(g) -> loads (the next fragment, weight DMA in groups 0 .. 3) -> unpack of group g + 1 (the operand is free once the
+    MFMA has issued) -> the FMAs of group g - 1 -> the row scales of groups g, g + 1 (even g: they may only change once the FMAs of
+    group g - 1 have read the old ones) -> the token scales of group g.  The scales of a whole super-block are copied by LDS-DMA one
+    iteration ahead into the second of two tables (the two-tile loops' token-tile-1 table)."""
+    global F, R1, T1
+    fmt = fmt or Q4K_R1
+    F, R1, T1 = fmt, True, True
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    for s in (S_256, S_256 + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0x43800000")
+    a.i(f"s_mov_b32 {sr(S_MASK0F)}, 0x0f0f0f0f")
+    a.i(f"s_mov_b32 {sr(S_MASK10)}, 0x10101010")
+    a.i(f"s_mov_b32 {sr(S_1024)}, 0x44800000")
+    a.i(f"v_cmp_ne_u32_e64 {sr(S_HI, 2)}, {F.QS_OFF}, {vr(V_HOFF)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_LDS)}")
+    a.i(f"s_add_u32 {sr(S_NSTAGE)}, {sr(S_LDS)}, {F.STAGE}")
+    a.i(f"s_mov_b32 {sr(S_WKN)}, {sr(S_WK)}")
+    for j in range(F.N_DMA):
+        dma_instr(a, j, S_STAGE)
+    a.vmem(f"buffer_load_dwordx4 {vr(S8[0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_S8)} offen", "s8_0")
+    t1_common_prologue(a)
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
+    a.i(f"v_add_u32 {vr(V_LDSWN)}, {F.STAGE}, {vr(V_LDSW0)}")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")
+    a.wait_vm("dma")
+    hdr_read(a, 0)
+    if F.Q5:
+        a.i(f"v_subrev_u32 {vr(T_HD)}, 32, {vr(V_LDSW)}")
+        a.lds(f"ds_read_b128 {vr(QH, 4)}, {vr(T_HD)}", "qh")
+    a.lds(f"ds_read_b128 {vr(RAW[0], 4)}, {vr(V_LDSW)} offset:0", "raw0")
+    hdr_decode(a, 0)
+    w_lo(a, 0, 0)
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    Asm.armed = True
+    a.i(f"L_sb_{label}%=:")
+    if a.vm[:1] == ["s8_0"]:
+        a.vm = a.vm[1:]
+    vm0, lg0 = list(a.vm), list(a.lg)
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
+    a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
+    for g in range(8):
+        q = g >> 1
+        mfma(a, g, 0)
+        if g == 1:
+            t1_d8_dma(a, True)                   # the next super-block's token scales into the other table (the last one: its own again,
+                                                 # harmless) — after group 0's read of THIS table, whose wait would otherwise cover it
+        t1_act_load(a, g)
+        for j in (2 * g, 2 * g + 1):
+            if j < F.N_DMA:
+                dma_instr(a, j, S_NSTAGE)
+        if g == 1:
+            bmin_prep(a, 0)
+        if g == 6:
+            a.wait_vm("dma")
+        if g % 2 == 0:
+            w_hi(a, 0, g + 1)
+            raw_read(a, 0, q + 1)
+        else:
+            if g == 7 and F.Q5:
+                a.wait_lg("qh")
+                for k in range(4):
+                    a.i(f"v_mov_b32 {vr(QH + k)}, {vr(QHN + k)}")
+            w_lo(a, 0, g + 1)
+        if g == 6:
+            hdr_read(a, 0)
+            if F.Q5:
+                a.i(f"v_subrev_u32 {vr(T_HD)}, 32, {vr(V_LDSWN)}")
+                a.lds(f"ds_read_b128 {vr(QHN, 4)}, {vr(T_HD)}", "qh")
+        pg = (g - 1) % 8
+        fma_block(a, pg, 0)
+        if g % 2 == 0:
+            dw_prep(a, q, 0)                     # (after the FMAs of group g - 1, which read the odd group's old scales)
+        t1_d8_reads(a, g)
+        if pg == 2:
+            min_mfma(a, 0)
+            a.i(f"v_cmp_nle_f32_e64 {sr(S_BIG, 2)}, |{vr(HDR[0] + 6)}|, {sr(S_1024)}")
+            a.i(f"s_cmp_lg_u64 {sr(S_BIG, 2)}, 0")
+            a.i(f"s_cbranch_scc1 L_cold_{label}%=")
+            a.i(f"L_warm_{label}%=:")
+            a.vmem(f"buffer_load_dwordx4 {vr(S8[0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_S8)} offen", "s8_0")
+        if g == 7:
+            hdr_decode(a, 0)
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_mov_b32 {sr(S_T1)}, 0x400")
+    a.i(f"s_xor_b32 {sr(S_DTAB)}, {sr(S_DTAB)}, {sr(S_T1)}")
+    a.i(f"v_xor_b32 {vr(V_LDSDT)}, {sr(S_T1)}, {vr(V_LDSDT)}")
+    a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
+    a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_NSTAGE)}")
+    a.i(f"s_mov_b32 {sr(S_NSTAGE)}, {sr(S_T0)}")
+    a.i(f"v_mov_b32 {vr(T_DW)}, {vr(V_LDSW)}")
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSWN)}")
+    a.i(f"v_mov_b32 {vr(V_LDSWN)}, {vr(T_DW)}")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSWN)}, {vr(V_HOFF)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.wait_lg("d8_0")                            # group 7's token scales: the top of the body reads them without a wait of its own
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
+    fma_block(a, 7, 0)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    a.i(f"s_branch L_end_{label}%=")
+    a.i(f"L_cold_{label}%=:")
+    bmin_prep(a, 0, scaled=True)
+    a.i("s_nop 7")
+    z = CSET[0]                                  # free here: group 2's FMAs are done (result set 0), MFMA(3) went to set 1, MFMA(4) comes after
+    a.i(f"v_mfma_f32_32x32x16_f16 {vr(z, 16)}, {vr(S8[0], 4)}, {vr(BMIN[0], 4)}, 0")
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    for j in range(0, 16, 2):
+        a.i(f"v_pk_fma_f32 {vr(ACC + j, 2)}, {vr(z + j, 2)}, {sr(S_256, 2)}, {vr(ACC + j, 2)}")
+    a.i("s_nop 3")
+    a.i(f"s_branch L_warm_{label}%=")
+    a.i(f"L_end_{label}%=:")
+    F, R1, T1 = Q4K, False, False
+    return a
+
+
 def q80_reads(a, rt, g):
     """the two aligned chunks that hold group g's quant bytes of this lane's row and K half, and the block's d (g = 8, 9: groups 0, 1 of
     the next 256 elements; stage buffer = (g >> 2) & 1)"""
@@ -1235,7 +1418,7 @@ def emit(a, fn_name):
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
     clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
     s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1,
-             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_MASK10, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
+             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_MASK10, S_DTAB, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
     clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
     return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
 static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,
@@ -1259,6 +1442,8 @@ if __name__ == "__main__":
     b = gen_q80("q80")
     c = gen_r1("r1_q4k_")
     g5 = gen_r1("r1_q5k_", Q5K_R1)
+    t4 = gen_t1("t1_q4k_")
+    t5 = gen_t1("t1_q5k_", Q5K_R1)
     d = gen_q80_r1("r1_q80_")
     e4 = gen_q40("q40_")
     f4 = gen_q40_r1("r1_q40_")
@@ -1272,4 +1457,6 @@ if __name__ == "__main__":
         f.write(emit(e4, "x64_loop_q40"))
         f.write(emit(f4, "x64_loop_q40_r1"))
         f.write(emit(g5, "x64_loop_q5k_r1"))
+        f.write(emit(t4, "x64_loop_q4k_t1"))
+        f.write(emit(t5, "x64_loop_q5k_t1"))
     print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)
