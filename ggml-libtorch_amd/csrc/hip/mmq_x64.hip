@@ -116,7 +116,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
   const int n0 = row_tile * UROWS, nb = n0 + (R3 && one_tile ? 64 : 0);
   const int r = lane & 31, h = lane >> 5;
   const int n_sb = k / 256;
-  const int sb_begin = (int)((int64_t)ks * n_sb / KS), sb_end = (int)((int64_t)(ks + 1) * n_sb / KS);
+  // K-slices are INTERLEAVED: slice ks takes the super-blocks ks, ks + KS, ks + 2 KS ... — at every K step the waves of a workgroup
+  // read KS adjacent super-blocks of each row (576 contiguous bytes with four slices of Q4_K: whole 64-byte lines, each fetched once;
+  // with blocked slices the 144-byte pieces 2304 bytes apart cost 1.19 x the algorithmic HBM traffic, profiles/r04_traffic.json)
+  const int sb_begin = ks, n_own = ks < n_sb ? (n_sb - ks + KS - 1) / KS : 0;
   const uint32_t row_bytes = (uint32_t)(k / Fmt<T>::QK) * Fmt<T>::BS;
   const int valid_rows = min(one_tile ? 32 : 64, n_rows - nb);
   X64_STAMP(0);
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
 #pragma unroll
   for (int i = 0; i < 32; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 
-  if (sb_begin < sb_end && valid_rows > 0) {   // wave-uniform
+  if (n_own > 0 && valid_rows > 0) {   // wave-uniform
     v16i magic;
 #pragma unroll
     for (int i = 0; i < 16; ++i) magic[i] = 0x4B400000;
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q8, 0, (int)0xFFFFFFFFu, 0x00020000);
     // 32-token records per super-block (the scratch layout pads the batch to a multiple of 64 tokens)
     const uint32_t n_tt32 = TT == 2 ? 2u * (uint32_t)n_tok_tiles : 2u * (uint32_t)((batch + 63) / 64);
-    const uint32_t sbstride = n_tt32 * X64_REC;
+    const uint32_t sbstride = (uint32_t)KS * n_tt32 * X64_REC;          // scratch bytes from one of this wave's super-blocks to its next
     const uint32_t f0 = ((uint32_t)sb_begin * n_tt32 + (uint32_t)TT * (uint32_t)tok_tile) * X64_REC;
     using XF = X64Fmt<T>;
     const uint32_t ring = (uint32_t)(uintptr_t)lds + (U32 ? (uint32_t)ks * XF::WAVE_LDS_R1
@@ -152,43 +155,43 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
     // (lane 63 = chunk 0 of the next instruction's first row: both write the same bytes)
     const uint32_t dmaoff = (uint32_t)(lane / XF::CPR) * row_bytes + (uint32_t)(lane % XF::CPR) * 16u;
     const uint32_t ldsd = ring + 2 * (one_tile ? XF::STAGE_R1 : X64_STAGE) + (uint32_t)h * 64u;
-    const uint32_t nsb = (uint32_t)(sb_end - sb_begin);
+    const uint32_t nsb = (uint32_t)n_own;
     X64_STAMP(1);
     if constexpr (T == GGQ_TYPE_Q8_0) {   // 272 bytes of a row per 256 elements, in two 128-element stages at a 144-byte LDS pitch
       const uint32_t hoff = 16u * (uint32_t)h;
       if (one_tile)
         x64_loop_q80_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                        sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                        sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 272u);
       else
       x64_loop_q80(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                   sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                   sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 272u);
     } else if constexpr (T == GGQ_TYPE_Q5_K) {   // one-row-tile waves only; header 16 bytes, qh 32, quants from byte 48
       const uint32_t hoff = 48u + 16u * (uint32_t)h;
       if constexpr (TT == 1)
         x64_loop_q5k_t1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 176u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                        sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                        sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 176u);
       else
       x64_loop_q5k_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 176u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                      sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                      sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 176u);
     } else if constexpr (T == GGQ_TYPE_Q4_0) {   // 144 bytes of a row per 256 elements (eight 18-byte blocks): one stage; both lane halves read the same bytes
       const uint32_t hoff = 16u * (uint32_t)h;
       if (one_tile)
         x64_loop_q40_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
       else
         x64_loop_q40(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                     sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                     sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
     } else {
       const uint32_t hoff = 16u + 16u * (uint32_t)h;
       if constexpr (TT == 1)
         x64_loop_q4k_t1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
       else if (one_tile)
         x64_loop_q4k_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
       else
         x64_loop_q4k(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
-                     sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u);
+                     sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
     }
   }
 

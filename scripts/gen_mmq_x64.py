@@ -47,6 +47,7 @@ S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN = 54, 55, 56, 57, 58, 59
 S_NEGM, S_1024, S_MASK0F, S_HI = 60, 62, 63, 66                  # s[60:61] = -12582912.0f x 2; s[66:67] = lanes 32-63
 S_NEXT = 74                                                      # byte distance to the next super-block's records (0 on the last one of the slice)
 S_BIG, S_256, S_EXEC = 68, 70, 72                                # s[68:69] cold-path mask, s[70:71] = 256.0f x 2, s[72:73] saved exec
+S_WSTEP = 83                                                     # input: weight bytes from one K step of this wave to its next (K-slices are interleaved: slices x step bytes)
 REC = 10240        # bytes of one (super-block, 32-token tile) record of the scratch
 ROWS = 64
 # experiment switches (scripts only; the shipped .inc is generated with the defaults)
@@ -492,7 +493,7 @@ def gen(label):
     vm0, lg0 = list(a.vm), list(a.lg)
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")                                               # last super-block of the slice?
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")                              # then "next" = this one again (harmless re-read)
-    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")                                        # (both selects before anything rewrites SCC)
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {sr(S_WSTEP)}")                                        # (both selects before anything rewrites SCC)
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
     a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
@@ -556,7 +557,7 @@ def gen(label):
                 a.i(f"L_warm_{label}%=:")
                 s8_loads(a)                      # s8 of the next super-block (the S8 registers are free now)
     # stage swap + loop control
-    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
     a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
     a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
@@ -660,7 +661,7 @@ def gen_r1(label, fmt=None):
     vm0, lg0 = list(a.vm), list(a.lg)
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
-    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {sr(S_WSTEP)}")
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
     a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
@@ -718,7 +719,7 @@ def gen_r1(label, fmt=None):
         d8_reads(a, 0, (g + 1) % 8)
         if g == 2:
             min_mfma(a, 0)
-    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
     a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
     a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
@@ -851,7 +852,7 @@ def gen_t1(label, fmt=None):
     vm0, lg0 = list(a.vm), list(a.lg)
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
-    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {sr(S_WSTEP)}")
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_add_u32 {sr(S_S8)}, {sr(S_S8)}, {sr(S_T0)}")
     a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
@@ -898,7 +899,7 @@ def gen_t1(label, fmt=None):
             a.vmem(f"buffer_load_dwordx4 {vr(S8[0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_S8)} offen", "s8_0")
         if g == 7:
             hdr_decode(a, 0)
-    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
     a.i(f"s_mov_b32 {sr(S_T1)}, 0x400")
     a.i(f"s_xor_b32 {sr(S_DTAB)}, {sr(S_DTAB)}, {sr(S_T1)}")
@@ -1031,7 +1032,7 @@ def gen_q80(label):
     vm0, lg0 = list(a.vm), list(a.lg)
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
-    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {2 * F.BS}")
+    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {sr(S_WSTEP)}")
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
     for g in range(8):
@@ -1076,7 +1077,7 @@ def gen_q80(label):
                 d8_reads(a, 0, (pg + 1) % 8)
             if pti == 3:
                 d8_reads(a, 1, (pg + 1) % 8)
-    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {2 * F.BS}")
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
     a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
     a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
@@ -1132,7 +1133,7 @@ def gen_q80_r1(label):
     vm0, lg0 = list(a.vm), list(a.lg)
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
-    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {2 * F.BS}")
+    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {sr(S_WSTEP)}")
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
     for g in range(8):
@@ -1172,7 +1173,7 @@ def gen_q80_r1(label):
             d8_dma(a, 1, 1, True)
         fma_block(a, g, 0)
         d8_reads(a, 0, (g + 1) % 8)
-    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {2 * F.BS}")
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
     a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
     a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
@@ -1246,7 +1247,7 @@ def q40_prologue_consts(a):
 
 
 def q40_loop_end(a):
-    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {F.BS}")
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
     a.i(f"s_add_u32 {sr(S_D1)}, {sr(S_D1)}, {sr(S_NEXT)}")
     a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
@@ -1262,7 +1263,7 @@ def q40_loop_end(a):
 def q40_loop_top(a):
     a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
     a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
-    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {F.BS}")
+    a.i(f"s_cselect_b32 {sr(S_T1)}, 0, {sr(S_WSTEP)}")
     a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
     a.i(f"s_add_u32 {sr(S_WKN)}, {sr(S_WK)}, {sr(S_T1)}")
     a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
@@ -1424,14 +1425,14 @@ def emit(a, fn_name):
 static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,
                                                unsigned hoff, unsigned dmaoff, __amdgpu_buffer_rsrc_t wrsrc, __amdgpu_buffer_rsrc_t arsrc,
                                                unsigned lds, unsigned nsb, unsigned sbstride, unsigned wk, unsigned rb7, unsigned f0,
-                                               unsigned f1, unsigned d0, unsigned d1, unsigned s8) {{
+                                               unsigned f1, unsigned d0, unsigned d1, unsigned s8, unsigned wstep) {{
   asm volatile(
 {asm}
       : "+{{v[0:31]}}"(acc0), "+{{v[32:63]}}"(acc1), "+{{s{S_NSB}}}"(nsb), "+{{s{S_WK}}}"(wk), "+{{s{S_F0}}}"(f0), "+{{s{S_F1}}}"(f1),
         "+{{s{S_D0}}}"(d0), "+{{s{S_D1}}}"(d1), "+{{s{S_S8}}}"(s8)
       : "{{v[{MAGICV}:{MAGICV + 15}]}}"(magic), "{{v{V_LANE16}}}"(lane16), "{{v{V_LDSD}}}"(ldsd), "{{v{V_LDSW0}}}"(ldsw0), "{{v{V_HOFF}}}"(hoff),
         "{{v{V_DMAOFF}}}"(dmaoff), "{{s[{S_WRSRC}:{S_WRSRC + 3}]}}"(wrsrc), "{{s[{S_ARSRC}:{S_ARSRC + 3}]}}"(arsrc), "{{s{S_LDS}}}"(lds),
-        "{{s{S_SBSTRIDE}}}"(sbstride), "{{s{S_RB7}}}"(rb7)
+        "{{s{S_SBSTRIDE}}}"(sbstride), "{{s{S_RB7}}}"(rb7), "{{s{S_WSTEP}}}"(wstep)
       : "memory", "scc", "vcc", "m0", "exec", {clob_s}, {clob_v});
 }}
 '''
