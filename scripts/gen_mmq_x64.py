@@ -761,7 +761,9 @@ def gen_r1(label, fmt=None):
 
 
 V_LDSDT = 214                # one-tile loops: LDS address of the CURRENT super-block's token-scale table (two tables, used alternately)
+V_DSUM = 215                 # ... the sum of this lane's two table addresses (the other table = sum - this one)
 S_DTAB = 82                  # ... LDS address of the table the next super-block's scales are copied into
+S_DSUM = 84                  # ... the sum of the two tables' addresses
 
 
 def t1_d8_dma(a, nxt):
@@ -787,7 +789,11 @@ def t1_d8_reads(a, target):
 
 def t1_common_prologue(a):
     a.i(f"s_add_u32 {sr(S_DTAB)}, {sr(S_LDS)}, {2 * F.STAGE}")
+    a.i(f"s_lshl_b32 {sr(S_DSUM)}, {sr(S_DTAB)}, 1")
+    a.i(f"s_add_u32 {sr(S_DSUM)}, {sr(S_DSUM)}, 1024")
     a.i(f"v_mov_b32 {vr(V_LDSDT)}, {vr(V_LDSD)}")
+    a.i(f"v_lshlrev_b32 {vr(V_DSUM)}, 1, {vr(V_LDSD)}")
+    a.i(f"v_add_u32 {vr(V_DSUM)}, 1024, {vr(V_DSUM)}")
     a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
     t1_d8_dma(a, False)                                           # the first super-block's scales -> table 0
     a.i(f"s_add_u32 {sr(S_DTAB)}, {sr(S_DTAB)}, 1024")             # the next one's go to table 1
@@ -901,9 +907,8 @@ def gen_t1(label, fmt=None):
             hdr_decode(a, 0)
     a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
     a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
-    a.i(f"s_mov_b32 {sr(S_T1)}, 0x400")
-    a.i(f"s_xor_b32 {sr(S_DTAB)}, {sr(S_DTAB)}, {sr(S_T1)}")
-    a.i(f"v_xor_b32 {vr(V_LDSDT)}, {sr(S_T1)}, {vr(V_LDSDT)}")
+    a.i(f"s_sub_u32 {sr(S_DTAB)}, {sr(S_DSUM)}, {sr(S_DTAB)}")     # the other table (an xor of 0x400 is NOT it: the tables' addresses are not 2 KB-aligned)
+    a.i(f"v_sub_u32 {vr(V_LDSDT)}, {vr(V_DSUM)}, {vr(V_LDSDT)}")
     a.i(f"s_mov_b32 {sr(S_T0)}, {sr(S_STAGE)}")
     a.i(f"s_mov_b32 {sr(S_STAGE)}, {sr(S_NSTAGE)}")
     a.i(f"s_mov_b32 {sr(S_NSTAGE)}, {sr(S_T0)}")
@@ -1419,7 +1424,7 @@ def emit(a, fn_name):
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
     clob_v = ", ".join(f'"v{i}"' for i in sorted(outs_v))
     s_mod = {S_T0, S_T1, S_STAGE, S_NSTAGE, S_INC6, S_WKN, S_NEGM, S_NEGM + 1, S_1024, S_MASK0F, S_HI, S_HI + 1, S_BIG, S_BIG + 1, S_256, S_256 + 1,
-             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_MASK10, S_DTAB, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
+             S_EXEC, S_EXEC + 1, S_NEXT, S_RUNA, S_RUNB, S_NEXTW, S_MASKF0, S_MASK10, S_DTAB, S_DSUM, S_SIXTEENTH, S_SIXTEENTH + 1, S_NEGM16, S_NEGM16 + 1}
     clob_s = ", ".join(f'"s{i}"' for i in sorted(s_mod))
     return f'''// GENERATED by scripts/gen_mmq_x64.py — do not edit.  {len(a.lines)} instructions.
 static __device__ __forceinline__ void {fn_name}(v32f& acc0, v32f& acc1, const v16i& magic, unsigned lane16, unsigned ldsd, unsigned ldsw0,

@@ -75,9 +75,10 @@ def test_mmq_routing_table():
                 # the 64 x 64 wave tiles: from 33 tokens, where the launch has at least 160 units of 64 rows — or, with the kernel's 32-row
                 # units, at least 192 (Q4_K) / 64 (Q8_0, Q4_0) units of 32 rows — for the formats the kernel serves
                 big_enough = units64(b, n) >= 160 or units32(b, n) >= {Q4_K: 192, Q5_K: 128, Q8_0: 64, Q4_0: 64}.get(int(t), 1 << 62)
+                one_tile = 17 <= b <= 32 and int(t) in (Q4_K, Q5_K) and -(-n // 32) >= 256   # batch 17 - 32 on many rows: the one-tile loops
                 if r == X64:
-                    assert b >= 33 and k % 256 == 0 and big_enough and L.ggq_mmq_x64_supported(int(t), k, b) == 1
-                elif b >= 33 and k % 256 == 0 and big_enough:
+                    assert k % 256 == 0 and ((b >= 33 and big_enough) or one_tile) and L.ggq_mmq_x64_supported(int(t), k, b) == 1
+                elif k % 256 == 0 and ((b >= 33 and big_enough) or one_tile):
                     assert L.ggq_mmq_x64_supported(int(t), k, b) == 0
                 if r == T16:
                     assert k % 256 == 0 and (1 if n < 8192 else 2) <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
@@ -89,7 +90,7 @@ def test_mmq_routing_table():
         for b in (2, 5, 8, 16):
             assert L.ggq_mmq_route(Q4_K, b, k, n) == T16 and L.ggq_mmq_route(Q5_K, b, k, n) == T16
         # two token tiles per wave (batch 17 - 32): up to 4096 rows, or where the streamed launch would leave a third of its CU-rounds empty
-        two = T16 if n in (11008, 4096, 3584) else STREAM
+        two = X64 if n >= 8161 else T16   # (shapes here: 11008 / 28672 rows -> the x64 kernel's one-tile loops; 4096 / 3584 -> 16-token tiles)
         assert L.ggq_mmq_route(Q4_K, 32, k, n) == two and L.ggq_mmq_route(Q5_K, 17, k, n) == two
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if n >= 32 * 191 + 1 else STREAM)
@@ -118,8 +119,8 @@ def test_mmq_routing_table():
                     dot4_to = (4 if n <= 12288 else 1) if t32 == Q3_K else 8   # Q3_K: streamed from batch 5, from 2 past 12288 rows
                     assert r == (DOT4 if b <= dot4_to else (LDS_TILE if t32 == Q8_0 else STREAM))
             assert L.ggq_mmq_route(t32, 17, k, n) != T16
-    for n, want in ((2048, T16), (4096, T16), (4128, STREAM), (6144, STREAM), (8192, STREAM), (8224, T16), (11008, T16), (11488, STREAM), (14336, STREAM),
-                    (16384, STREAM), (16416, T16), (28672, STREAM)):
+    for n, want in ((2048, T16), (4096, T16), (4128, STREAM), (6144, STREAM), (8160, STREAM), (8161, X64), (8192, X64), (8224, X64), (11008, X64), (11488, X64),
+                    (14336, X64), (16384, X64), (16416, X64), (28672, X64)):
         assert L.ggq_mmq_route(Q4_K, 32, 4096, n) == want and L.ggq_mmq_route(Q5_K, 32, 8192, n) == want, n
         assert L.ggq_mmq_route(Q4_K, 16, 4096, n) == T16
     assert [L.ggq_mmq_route(Q6_K, 8, 4096, n) for n in (16384, 32768, 32769, 128256)] == [T16, T16, DOT4, DOT4]
@@ -183,6 +184,25 @@ def test_route_regret_with_32_row_units():
         assert pts >= 60, (name, pts)
 
 
+def test_route_regret_batch_17_32():
+    """profiles/r04b_x64_one_tile_b17_32.txt: the x64 kernel's one-tile loops against what the route took before them (16-token tiles /
+    streamed kernel), Q4_K and Q5_K, six shapes, batch 17 and 32, op us cold: the route's choice is within 10 % of the faster one"""
+    import re
+    from ggq import lib as ggqlib
+    L = ggqlib.cpu()
+    pts = 0
+    for line in open(os.path.join(ROOT, "profiles", "r04b_x64_one_tile_b17_32.txt")):
+        m = re.match(r"type (\d+) (\d+)x(\d+) batch (\d+): .*x64 op warm ([\d.]+)\s+x64 op cold ([\d.]+)\s+old op warm ([\d.]+)\s+old op cold ([\d.]+)", line)
+        if not m:
+            continue
+        t, n, k, b = (int(m.group(i)) for i in range(1, 5))
+        x64_cold, old_cold = float(m.group(6)), float(m.group(8))
+        chosen = x64_cold if L.ggq_mmq_route(t, b, k, n) == 5 else old_cold
+        assert chosen <= 1.10 * min(x64_cold, old_cold), (t, n, k, b, chosen)
+        pts += 1
+    assert pts == 24
+
+
 def test_x64_launch_shape_rules():
     """K-slices and rows per unit of the 64 x 64 wave-tile kernel (ggq_mmq_x64_k_slices / ggq_mmq_x64_unit_rows): eight slices while a
     unit has a CU to itself; 96-row units exactly where 64-row units would need a second workgroup on some CUs and 96-row units do
@@ -197,6 +217,7 @@ def test_x64_launch_shape_rules():
                           (128, 4096, 28672, 64), (65, 1024, 8230, 96), (128, 4096, 4096, 32), (64, 4096, 8192, 32), (64, 4096, 10176, 32),
                           (64, 4096, 10177, 64), (128, 4096, 5120, 64), (128, 4096, 5056, 32), (33, 256, 64, 32)):
         assert L.ggq_mmq_x64_unit_rows(Q4_K, b, k, n) == want, (b, k, n)
+        assert L.ggq_mmq_x64_unit_rows(Q4_K, 32, k, n) == 32 and L.ggq_mmq_x64_unit_rows(13, b, k, n) == 32   # one token tile / Q5_K: 32-row units always
         assert L.ggq_mmq_x64_unit_rows(Q8_0, b, k, n) == want and L.ggq_mmq_x64_unit_rows(14, b, k, n) == 64   # (Q6_K: not an x64 format)
         tt = -(-b // 64)
         if want == 96:

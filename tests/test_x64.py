@@ -44,7 +44,9 @@ def test_quantize_q8_1_x64_bit_exact(oracle, dtype, t, batch, k):
 @pytest.mark.parametrize("dtype", DTYPES, ids=str)
 @pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
 @pytest.mark.parametrize("batch,k,n_rows", [(1, 256, 33), (33, 256, 64), (64, 1024, 64), (40, 4096, 130), (65, 768, 31), (128, 2304, 70),
-                                            (100, 1280, 95), (129, 512, 200), (70, 11008, 40), (36, 16384, 65)])
+                                            (100, 1280, 95), (129, 512, 200), (70, 11008, 40), (36, 16384, 65),
+                                            # batches up to 32 tokens with several super-blocks per K-slice (the one-tile loops where they exist)
+                                            (17, 2048, 100), (32, 4096, 70), (24, 1280, 40), (9, 8192, 64), (32, 11008, 33)])
 def test_mmq_x64_vs_oracle(oracle, dtype, t, batch, k, n_rows):
     """ragged row tiles and token tiles; 1, 2, 3, 4 ... 64 super-blocks: K-slices of zero, equal and unequal length"""
     assert ggqlib.hip().ggq_mmq_x64_supported(int(t), k, batch) == 1
@@ -127,7 +129,13 @@ def test_mmq_x64_integer_exact(oracle, t):
     the last bit (integer unpack, operand order and the int8 MFMA contraction)"""
     from ggq.synth import _F16_FIELDS
     qk, bs = BLOCK[t]
-    n_rows, k, batch = 96, 1024, 70
+    _integer_exact(oracle, t, 96, 1024, 70)
+    _integer_exact(oracle, t, 70, 2048, 20)   # (up to 32 tokens: the one-tile loops, two super-blocks per K-slice)
+
+
+def _integer_exact(oracle, t, n_rows, k, batch):
+    from ggq.synth import _F16_FIELDS
+    qk, bs = BLOCK[t]
     w = synth.random_weight(t, n_rows, k, seed=9).reshape(-1, bs)
     d_off, m_off = _F16_FIELDS[t]
     w[:, d_off:d_off + 2] = np.array([2.0 ** -4], np.float16).view(np.uint8)
