@@ -149,13 +149,14 @@ def _integer_exact(oracle, t, n_rows, k, batch):
     assert np.array_equal(y, ref), f"{t.name}: exact-integer x64 MMQ differs"
 
 
+@pytest.mark.parametrize("batch", [40, 20, 128])   # 20: the one-tile loops; 128 with 768 rows: 64-row... 32-row units (both row-tile kinds via 96-row tests)
 @pytest.mark.parametrize("t", [t for t in X64_TYPES if t in (GGMLType.Q4_K, GGMLType.Q5_K)], ids=lambda t: t.name)
-def test_mmq_x64_min_scale_range(oracle, t):
+def test_mmq_x64_min_scale_range(oracle, t, batch):
     """the min term's exact hi + lo fp16 split over the whole range of dmin: subnormal remainders, the 1024 threshold of the
     2^-8-scaled cold pass (rows above and below it in ONE tile), fp16 max, negative and zero dmin"""
     from ggq.synth import _F16_FIELDS
     qk, bs = BLOCK[t]
-    n_rows, k, batch = 70, 768, 40
+    n_rows, k = 70, 768 if batch != 20 else 2048
     w = synth.random_weight(t, n_rows, k, seed=3).reshape(n_rows, -1, bs)
     _, m_off = _F16_FIELDS[t]
     vals = np.array([6e-8, 6.1e-5, 1.0, 1023.5, 1024.0, 1024.5, 65504.0, -65504.0, -3.0, 0.0, 2.0 ** -14, -2000.0], np.float16)
@@ -167,6 +168,9 @@ def test_mmq_x64_min_scale_range(oracle, t):
     y = util.gpu_mmq_x64(w, x, t, n_rows)
     ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
     util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"x64 min-term range {t.name}")
+    if batch == 20:   # the one-tile loops against the two-tile loops: the same tokens inside a 40-token launch (same units, same K-slices), bit for bit
+        x40 = torch.cat([x, _x((20, k), torch.float32, seed=5)])
+        assert torch.equal(util.gpu_mmq_x64(w, x40, t, n_rows)[:20], y), "one-tile and two-tile loops differ"
 
 
 def test_mmq_x64_ldy_epilogues_unaligned_and_errors(oracle):
