@@ -120,7 +120,7 @@ extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
 extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows) {
   if (!ggq_mmq_x64_type_supported(type)) return 64;
   if (type == GGQ_TYPE_Q5_K) return 32;   // its 176-byte super-blocks fit the LDS as 32-row stages only (mmq_x64.hip, X64Fmt)
-  if (type == GGQ_TYPE_Q4_K && batch <= 32) return 32;   // one 32-token tile: the one-tile loop (32 rows x 32 tokens per wave)
+  if (ggq_mmq_x64_type_supported(type) && batch <= 32) return 32;   // one 32-token tile: the one-tile loops (32 rows x 32 tokens per wave)
   const int64_t tt = (batch + 63) / 64;
   const int64_t u64 = ((n_rows + 63) / 64) * tt, u96 = ((n_rows + 95) / 96) * tt;
   if (u64 < 160) return 32;
@@ -214,9 +214,14 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // (8192-row matrices) the x64 kernel is ahead of the 16-token tiles / the streamed kernel, op us warm / cold (profiles/r04b_x64_one_tile_b17_32.txt):
   // Q4_K 8192 x 4096 10.5 / 12.6 against 11.1 / 14.4, 14336 15.3 / 17.7 against 15.9 / 20.3, 28672 28.4 / 31.3 against 28.7 / 35.2, 11008 14.4 / 17.1 against
   // 15.4 / 17.6; Q5_K 8192 10.6 / 13.3 against 12.0 / 15.6; below (4096 x 4096, 3584 x 8192) it loses 15 - 25 %.
-  if (batch >= 17 && batch <= 32 && (type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K) && ggq_mmq_x64_supported(type, k, batch) &&
-      (n_rows + 31) / 32 >= 256)
-    return GGQ_MMQ_ROUTE_X64;
+  // Q8_0 / Q4_0 (profiles/r04b_x64_one_tile_b17_32_q80_q40.txt; before: the LDS-tile / streamed kernels): ahead at all six measured shapes —
+  // Q8_0 8192 x 4096 13.2 / 15.8 against 18.7 / 22.9, 4096 x 4096 10.8 / 14.1 against 14.2 / 18.5, 3584 x 8192 16.6 / 21.4 against 22.4 / 27.9, 11008 17.5 / 23.1 against
+  // 21.2 / 25.2; Q4_0 8192 10.9 / 12.8 against 12.5 / 17.0, 4096 x 4096 10.6 / 12.1 against 12.3 / 16.3, 28672 level — from 112 units of 32 rows (3584 rows, the
+  // smallest measured).
+  if (batch >= 17 && batch <= 32 && ggq_mmq_x64_supported(type, k, batch)) {
+    const int64_t u32 = (n_rows + 31) / 32;
+    if ((type == GGQ_TYPE_Q4_K || type == GGQ_TYPE_Q5_K) ? u32 >= 256 : u32 >= 112) return GGQ_MMQ_ROUTE_X64;
+  }
   // The HBM-bound batches.  Measured (scripts/sweep_t16.py, op = quantise + kernel, us warm / cold, old route -> 16-token tiles):
   //   Q4_K 11008 x 4096   b2  8.8/11.6 ->  9.0/12.0   b3 10.4/12.8 -> 8.9/12.0   b8 15.2/16.4 -> 9.3/12.2   b16 15.8/19.9 -> 11.6/13.9
   //                       b32 15.8/19.7 -> 15.0/17.9  b33 20.4/24.0 -> 23.0/25.1

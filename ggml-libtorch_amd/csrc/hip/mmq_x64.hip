@@ -87,7 +87,7 @@ template <int T> struct X64Fmt {
   static constexpr int CPR = PITCH / 16, RPI = 63 / CPR;            // 16-byte chunks per row; rows one DMA instruction covers
   static constexpr int STAGE_R1 = 32 * PITCH, WAVE_LDS_R1 = 2 * STAGE_R1 + 2048;
   static constexpr bool ONLY_32 = T == GGQ_TYPE_Q5_K;
-  static constexpr bool HAS_T1 = T == GGQ_TYPE_Q4_K || T == GGQ_TYPE_Q5_K;   // a one-tile loop (32 rows x 32 tokens per wave) exists
+  static constexpr bool HAS_T1 = true;   // a one-tile loop (32 rows x 32 tokens per wave) exists for every format of the kernel
 };
 
 // UR = weight rows per unit: 64; 96 (R3, above); 32 (U32: every wave a one-row-tile wave — the form for launches with too few 64-row
@@ -159,7 +159,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
     X64_STAMP(1);
     if constexpr (T == GGQ_TYPE_Q8_0) {   // 272 bytes of a row per 256 elements, in two 128-element stages at a 144-byte LDS pitch
       const uint32_t hoff = 16u * (uint32_t)h;
-      if (one_tile)
+      if constexpr (TT == 1)
+        x64_loop_q80_t1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 272u);
+      else if (one_tile)
         x64_loop_q80_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u + hoff, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                         sbstride, (uint32_t)sb_begin * 272u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 272u);
       else
@@ -175,7 +178,10 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
                       sbstride, (uint32_t)sb_begin * 176u, 5u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 176u);
     } else if constexpr (T == GGQ_TYPE_Q4_0) {   // 144 bytes of a row per 256 elements (eight 18-byte blocks): one stage; both lane halves read the same bytes
       const uint32_t hoff = 16u * (uint32_t)h;
-      if (one_tile)
+      if constexpr (TT == 1)
+        x64_loop_q40_t1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
+                        sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
+      else if (one_tile)
         x64_loop_q40_r1(acc0, acc1, magic, (uint32_t)lane * 16u, ldsd, ring + (uint32_t)r * 144u, hoff, dmaoff, wrsrc, arsrc, ring, nsb,
                         sbstride, (uint32_t)sb_begin * 144u, 7u * row_bytes, f0, f0 + X64_REC, f0 + 8192u, f0 + X64_REC + 8192u, f0 + 9216u, (uint32_t)KS * 144u);
       else

@@ -787,7 +787,7 @@ def t1_d8_reads(a, target):
         a.lds(f"ds_read_b128 {vr(D8[0] + 4 * k, 4)}, {vr(V_LDSDT)} offset:{128 * target + 16 * k}", "d8_0" if k == 3 else "d8_0x")
 
 
-def t1_common_prologue(a):
+def t1_common_prologue(a, mid=None):
     a.i(f"s_add_u32 {sr(S_DTAB)}, {sr(S_LDS)}, {2 * F.STAGE}")
     a.i(f"s_lshl_b32 {sr(S_DSUM)}, {sr(S_DTAB)}, 1")
     a.i(f"s_add_u32 {sr(S_DSUM)}, {sr(S_DSUM)}, 1024")
@@ -797,6 +797,8 @@ def t1_common_prologue(a):
     a.i(f"s_mov_b32 {sr(S_NEXT)}, 0")
     t1_d8_dma(a, False)                                           # the first super-block's scales -> table 0
     a.i(f"s_add_u32 {sr(S_DTAB)}, {sr(S_DTAB)}, 1024")             # the next one's go to table 1
+    if mid:
+        mid()                                                     # (vector-memory operations that the loop body issues before its last fragment load)
     a.vmem(f"buffer_load_dwordx4 {vr(ACT[0][0], 4)}, {vr(V_LANE16)}, {sr(S_ARSRC, 4)}, {sr(S_F0)} offen", "act0_0")
     a.i(f"s_add_u32 {sr(S_F0)}, {sr(S_F0)}, 0x400")
     for k in range(16):
@@ -1419,6 +1421,123 @@ def gen_q40_r1(label):
     return a
 
 
+def gen_q80_t1(label):
+    """Q8_0, one MFMA tile per wave and group (32 rows x 32 tokens): gen_q80_r1 with one slot per group, as gen_t1 is to gen_r1."""
+    global F, R1, T1
+    F, R1, T1 = Q80_R1, True, True
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    a.i(f"v_sub_u32 {vr(V_LDSHN)}, {vr(V_LDSW0)}, {vr(V_HOFF)}")
+    a.i(f"v_mov_b32 {vr(V_LDSW)}, {vr(V_LDSW0)}")
+    a.i(f"s_mov_b32 {sr(S_RUNA)}, {sr(S_WK)}")
+    for j in range(F.N_DMA):
+        q80_dma(a, j, 0, S_RUNA, "dmaA")
+    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_WK)}, {F.BS}")
+    t1_common_prologue(a, lambda: [q80_dma(a, j, 1, S_RUNB, "dmaB") for j in range(3)])
+    for j in range(3, F.N_DMA):
+        q80_dma(a, j, 1, S_RUNB, "dmaB")
+    a.wait_vm("dmaA")
+    q80_reads(a, 0, 0)
+    q80_w_prep(a, 0, 0)
+    q80_reads(a, 0, 1)
+    Asm.armed = True
+    a.i(f"L_sb_{label}%=:")
+    vm0, lg0 = list(a.vm), list(a.lg)
+    a.i(f"s_cmp_eq_u32 {sr(S_NSB)}, 1")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, 0, {sr(S_SBSTRIDE)}")
+    a.i(f"s_cselect_b32 {sr(S_NEXTW)}, 0, {sr(S_WSTEP)}")
+    a.i(f"s_sub_u32 {sr(S_INC6)}, {sr(S_T0)}, {7 * 1024}")
+    a.i(f"s_mov_b32 {sr(S_NEXT)}, {sr(S_T0)}")
+    for g in range(8):
+        mfma(a, g, 0)
+        q80_dw_prep(a, 0, g)
+        if g == 1:
+            t1_d8_dma(a, True)
+        t1_act_load(a, g)
+        if g in (2, 3):                          # stage A of the next 256 elements (this iteration's last read of A: group 1)
+            for j in ((0, 1, 2) if g == 2 else (3, 4)):
+                if j == 0:
+                    a.i(f"s_add_u32 {sr(S_RUNA)}, {sr(S_WK)}, {sr(S_NEXTW)}")
+                q80_dma(a, j, 0, S_RUNA, "dmaA")
+        if g in (6, 7):                          # stage B of the next 256 elements (last read of B: group 5)
+            for j in ((0, 1, 2) if g == 6 else (3, 4)):
+                if j == 0:
+                    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_WK)}, {sr(S_NEXTW)}")
+                    a.i(f"s_add_u32 {sr(S_RUNB)}, {sr(S_RUNB)}, {F.BS}")
+                q80_dma(a, j, 1, S_RUNB, "dmaB")
+        if g == 2:
+            a.wait_vm("dmaB")
+        if g == 6:
+            a.wait_vm("dmaA")
+        q80_w_prep(a, 0, g + 1)
+        q80_reads(a, 0, g + 2)
+        fma_block(a, (g - 1) % 8, 0)
+        t1_d8_reads(a, g)
+    a.i(f"s_add_u32 {sr(S_WK)}, {sr(S_WK)}, {sr(S_WSTEP)}")
+    a.i(f"s_add_u32 {sr(S_D0)}, {sr(S_D0)}, {sr(S_NEXT)}")
+    a.i(f"s_sub_u32 {sr(S_DTAB)}, {sr(S_DSUM)}, {sr(S_DTAB)}")
+    a.i(f"v_sub_u32 {vr(V_LDSDT)}, {vr(V_DSUM)}, {vr(V_LDSDT)}")
+    a.i(f"s_sub_u32 {sr(S_NSB)}, {sr(S_NSB)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.wait_lg("d8_0")
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
+    fma_block(a, 7, 0)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    F, R1, T1 = Q4K, False, False
+    return a
+
+
+def gen_q40_t1(label):
+    """Q4_0, one MFMA tile per wave and group: gen_q40_r1 with one slot per group."""
+    global F, R1, T1
+    F, R1, T1 = Q40_R1, True, True
+    a = Asm()
+    for s in (S_NEGM, S_NEGM + 1):
+        a.i(f"s_mov_b32 {sr(s)}, 0xcb400000")
+    q40_prologue_consts(a)
+    for j in range(F.N_DMA):
+        dma_instr(a, j, S_STAGE)
+    t1_common_prologue(a)
+    a.wait_vm("dma")
+    q40_reads(a, 0, 0)
+    q40_w_prep(a, 0, 0)
+    q40_reads(a, 0, 1)
+    Asm.armed = True
+    a.i(f"L_sb_{label}%=:")
+    vm0, lg0 = list(a.vm), list(a.lg)
+    q40_loop_top(a)
+    for g in range(8):
+        mfma(a, g, 0)
+        q40_dw_prep(a, 0, g)
+        if g == 1:
+            t1_d8_dma(a, True)
+        t1_act_load(a, g)
+        for j in (2 * g, 2 * g + 1):
+            if j < F.N_DMA:
+                dma_instr(a, j, S_NSTAGE)
+        if g == 6:
+            a.wait_vm("dma")
+        q40_w_prep(a, 0, g + 1)
+        q40_reads(a, 0, g + 2)
+        fma_block(a, (g - 1) % 8, 0)
+        t1_d8_reads(a, g)
+    q40_loop_end(a)
+    a.i(f"s_sub_u32 {sr(S_DTAB)}, {sr(S_DSUM)}, {sr(S_DTAB)}")
+    a.i(f"v_sub_u32 {vr(V_LDSDT)}, {vr(V_DSUM)}, {vr(V_LDSDT)}")
+    a.i(f"s_cmp_lg_u32 {sr(S_NSB)}, 0")
+    a.wait_lg("d8_0")
+    a.i(f"s_cbranch_scc1 L_sb_{label}%=")
+    assert a.vm == vm0[len(vm0) - len(a.vm):] and a.lg == lg0[len(lg0) - len(a.lg):], (a.vm, vm0, a.lg, lg0)
+    Asm.armed = False
+    fma_block(a, 7, 0)
+    a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    F, R1, T1 = Q4K, False, False
+    return a
+
+
 def emit(a, fn_name):
     asm = "\n".join(f'      "{l}\\n"' for l in a.lines)
     outs_v = set(range(64, N_VGPR if X_INPLACE else 256)) - set(range(MAGICV, MAGICV + 16)) - {V_LANE16, V_LDSD, V_LDSW0, V_HOFF, V_DMAOFF}
@@ -1450,6 +1569,8 @@ if __name__ == "__main__":
     g5 = gen_r1("r1_q5k_", Q5K_R1)
     t4 = gen_t1("t1_q4k_")
     t5 = gen_t1("t1_q5k_", Q5K_R1)
+    t8 = gen_q80_t1("t1_q80_")
+    t0 = gen_q40_t1("t1_q40_")
     d = gen_q80_r1("r1_q80_")
     e4 = gen_q40("q40_")
     f4 = gen_q40_r1("r1_q40_")
@@ -1465,4 +1586,6 @@ if __name__ == "__main__":
         f.write(emit(g5, "x64_loop_q5k_r1"))
         f.write(emit(t4, "x64_loop_q4k_t1"))
         f.write(emit(t5, "x64_loop_q5k_t1"))
+        f.write(emit(t8, "x64_loop_q80_t1"))
+        f.write(emit(t0, "x64_loop_q40_t1"))
     print(len(a.lines), "+", len(b.lines), "instructions ->", OUT, file=sys.stderr)

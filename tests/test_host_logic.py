@@ -75,7 +75,7 @@ def test_mmq_routing_table():
                 # the 64 x 64 wave tiles: from 33 tokens, where the launch has at least 160 units of 64 rows — or, with the kernel's 32-row
                 # units, at least 192 (Q4_K) / 64 (Q8_0, Q4_0) units of 32 rows — for the formats the kernel serves
                 big_enough = units64(b, n) >= 160 or units32(b, n) >= {Q4_K: 192, Q5_K: 128, Q8_0: 64, Q4_0: 64}.get(int(t), 1 << 62)
-                one_tile = 17 <= b <= 32 and int(t) in (Q4_K, Q5_K) and -(-n // 32) >= 256   # batch 17 - 32 on many rows: the one-tile loops
+                one_tile = 17 <= b <= 32 and -(-n // 32) >= {Q4_K: 256, Q5_K: 256, Q8_0: 112, Q4_0: 112}.get(int(t), 1 << 62)   # batch 17 - 32: the one-tile loops
                 if r == X64:
                     assert k % 256 == 0 and ((b >= 33 and big_enough) or one_tile) and L.ggq_mmq_x64_supported(int(t), k, b) == 1
                 elif k % 256 == 0 and ((b >= 33 and big_enough) or one_tile):
@@ -97,7 +97,8 @@ def test_mmq_routing_table():
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == (X64 if n >= 32 * 95 + 1 else STREAM) and L.ggq_mmq_route(Q4_K, 4096, k, n) == X64
         mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows ...
         big = lambda b: X64 if (units64(b, n) >= 160 or units32(b, n) >= 64) else None   # ... and from 33 tokens the x64 kernel (32-row units from 64 of them)
-        assert L.ggq_mmq_route(Q8_0, 17, k, n) == mid8 and L.ggq_mmq_route(Q8_0, 64, k, n) == (big(64) or mid8)
+        assert L.ggq_mmq_route(Q8_0, 17, k, n) == X64 and L.ggq_mmq_route(Q8_0, 64, k, n) == (big(64) or mid8)   # 17 - 32: the one-tile loops from 3584 rows
+        assert L.ggq_mmq_route(Q8_0, 17, k, 3552) == STREAM   # (below 112 units of 32 rows; few rows: the streamed kernel)
         assert L.ggq_mmq_route(Q8_0, 65, k, n) == (big(65) or STREAM)
         assert L.ggq_mmq_route(Q6_K, 32, k, n) == LDS_TILE and L.ggq_mmq_route(Q6_K, 33, k, n) == STREAM and L.ggq_mmq_route(Q6_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
         assert all(L.ggq_mmq_route(Q6_K, b, k, n) == T16 for b in (2, 8)) and L.ggq_mmq_route(Q6_K, 17, k, n) == LDS_TILE
@@ -105,7 +106,7 @@ def test_mmq_routing_table():
         # Q2_K: dot4 to batch 4 (2 with few rows), streamed to 16 and from 33, the LDS-tile kernel in between
         assert [L.ggq_mmq_route(10, b, k, n) for b in (2, 3, 4, 5, 16, 17, 32, 33, 128)] == \
             [DOT4, DOT4 if 8192 <= n <= 12288 else STREAM, DOT4 if 8192 <= n <= 12288 else STREAM, STREAM, STREAM, LDS_TILE, LDS_TILE, STREAM, STREAM]
-        assert L.ggq_mmq_route(Q4_0, 17, k, n) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == (DOT4 if n >= 8192 else T16)
+        assert L.ggq_mmq_route(Q4_0, 17, k, n) == X64 and L.ggq_mmq_route(Q4_0, 17, k, 3552) == STREAM and L.ggq_mmq_route(Q4_0, 1, k, n) == (DOT4 if n >= 8192 else T16)
         # the 32-element-block formats: 16-token tiles up to batch 16 — from batch 2 when the matrix has few rows, from where
         # the dot4 kernel stops scaling (5 / 9 / never) when it has many
         many = n >= 8192
@@ -186,12 +187,14 @@ def test_route_regret_with_32_row_units():
 
 def test_route_regret_batch_17_32():
     """profiles/r04b_x64_one_tile_b17_32.txt: the x64 kernel's one-tile loops against what the route took before them (16-token tiles /
-    streamed kernel), Q4_K and Q5_K, six shapes, batch 17 and 32, op us cold: the route's choice is within 10 % of the faster one"""
+    streamed / LDS-tile kernel), Q4_K, Q5_K, Q8_0 and Q4_0, six shapes, batch 17 and 32, op us cold: the route's choice is within 10 % of the
+    faster one"""
     import re
     from ggq import lib as ggqlib
     L = ggqlib.cpu()
     pts = 0
-    for line in open(os.path.join(ROOT, "profiles", "r04b_x64_one_tile_b17_32.txt")):
+    lines = list(open(os.path.join(ROOT, "profiles", "r04b_x64_one_tile_b17_32.txt"))) + list(open(os.path.join(ROOT, "profiles", "r04b_x64_one_tile_b17_32_q80_q40.txt")))
+    for line in lines:
         m = re.match(r"type (\d+) (\d+)x(\d+) batch (\d+): .*x64 op warm ([\d.]+)\s+x64 op cold ([\d.]+)\s+old op warm ([\d.]+)\s+old op cold ([\d.]+)", line)
         if not m:
             continue
@@ -200,7 +203,7 @@ def test_route_regret_batch_17_32():
         chosen = x64_cold if L.ggq_mmq_route(t, b, k, n) == 5 else old_cold
         assert chosen <= 1.10 * min(x64_cold, old_cold), (t, n, k, b, chosen)
         pts += 1
-    assert pts == 24
+    assert pts == 48
 
 
 def test_x64_launch_shape_rules():
@@ -217,7 +220,7 @@ def test_x64_launch_shape_rules():
                           (128, 4096, 28672, 64), (65, 1024, 8230, 96), (128, 4096, 4096, 32), (64, 4096, 8192, 32), (64, 4096, 10176, 32),
                           (64, 4096, 10177, 64), (128, 4096, 5120, 64), (128, 4096, 5056, 32), (33, 256, 64, 32)):
         assert L.ggq_mmq_x64_unit_rows(Q4_K, b, k, n) == want, (b, k, n)
-        assert L.ggq_mmq_x64_unit_rows(Q4_K, 32, k, n) == 32 and L.ggq_mmq_x64_unit_rows(13, b, k, n) == 32   # one token tile / Q5_K: 32-row units always
+        assert L.ggq_mmq_x64_unit_rows(Q4_K, 32, k, n) == 32 and L.ggq_mmq_x64_unit_rows(Q8_0, 17, k, n) == 32 and L.ggq_mmq_x64_unit_rows(13, b, k, n) == 32   # one token tile / Q5_K: 32-row units always
         assert L.ggq_mmq_x64_unit_rows(Q8_0, b, k, n) == want and L.ggq_mmq_x64_unit_rows(14, b, k, n) == 64   # (Q6_K: not an x64 format)
         tt = -(-b // 64)
         if want == 96:
