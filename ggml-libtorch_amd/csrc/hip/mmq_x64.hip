@@ -1,4 +1,4 @@
-// mmq_x64.hip — quantised GEMM  Y[B,N] = X[B,K] (Q8_1) · W[N,K]^T for batches from 33 tokens up: 64-row x 64-token wave tiles,
+// mmq_x64.hip — quantised GEMM  Y[B,N] = X[B,K] (Q8_1) · W[N,K]^T for batches from 17 tokens up: 64-row x 64-token wave tiles (32 x 32 up to 32 tokens),
 // K loop in hand-scheduled gfx950 assembly (generated: scripts/gen_mmq_x64.py -> mmq_x64_loops.inc).
 //
 // Replaces, for the formats it serves, mul_mat_q's large-tile instances (HK/ggml/mmq.cuh:1917-1986 with mmq_x = 64 ... 128,
@@ -22,7 +22,12 @@
 //   min term Σ_g (-dmin·m_g)[row]·s8_g[token]: ONE v_mfma_f32_32x32x16_f16 per super-block and tile (exact hi + lo fp16 split, as in
 //     mmq_stream_kernel), rows with |dmin| > 1024 through a 2^-8-scaled cold pass;
 //   K-slice partial sums meet once in LDS and are added in slice order; the write-back reads them back transposed, so that a
-//     thread stores 16 consecutive rows of one token (32 contiguous bytes, a token's 64 rows = one 128-byte line).
+//     thread stores 16 consecutive rows of one token (32 contiguous bytes, a token's 64 rows = one 128-byte line);
+//   K-slices are interleaved (slice s: super-blocks s, s + KS, ...): the waves of a workgroup read adjacent super-blocks at every step;
+//   unit shapes (UR / TT template parameters; ggq_mmq_x64_unit_rows): 64 rows x 64 tokens as above; 96 rows (four two-row-tile waves + four
+//     one-row-tile waves) where that makes the launch one even round; 32 rows (one-row-tile waves only) for small launches and for Q5_K,
+//     whose 176-byte super-blocks fit the LDS as 32-row stages only; 32 rows x 32 tokens (one MFMA tile per wave and group) up to 32 tokens.
+//     Eleven generated loops: {Q4_K, Q8_0, Q4_0} x {2 x 2, 1 x 2, 1 x 1 tiles} and Q5_K x {1 x 2, 1 x 1}; bit-identical per (format, KS).
 #include "ggq_common.h"
 
 namespace ggq {

@@ -198,7 +198,7 @@ int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype
                       int64_t batch, int64_t k, int64_t n_rows, int64_t ldy,
                       int epilogue, const void* aux, void* stream);
 
-/* 64-row x 64-token wave tiles for the batches from 33 tokens up (round 4; the role of mul_mat_q's mmq_x = 64 ... 128 instances,
+/* 64-row x 64-token wave tiles for the batches from 33 tokens up — and, as 32-row x 32-token one-tile units, for 17 - 32 — (round 4; the role of mul_mat_q's mmq_x = 64 ... 128 instances,
  * HK/ggml/kernel_instances/mmq_kernel.cuh:21-32 + mmq.cuh:1917-1986, at the reference benchmark's own batch sizes,
  * benchmarks/benchmark_mmq.py:152).  K loop in hand-scheduled gfx950 assembly (scripts/gen_mmq_x64.py).  The scratch ("x64 layout",
  * ggq_quantize_q8_1_x64) holds the same Q8_1 values as ggq_quantize_q8_1_mmq, regrouped per (k/256, token/32) into 10240-byte records
