@@ -120,11 +120,21 @@ extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
 extern "C" int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows) {
   if (!ggq_mmq_x64_type_supported(type)) return 64;
   if (type == GGQ_TYPE_Q5_K) return 32;   // its 176-byte super-blocks fit the LDS as 32-row stages only (mmq_x64.hip, X64Fmt)
-  if (ggq_mmq_x64_type_supported(type) && batch <= 32) return 32;   // one 32-token tile: the one-tile loops (32 rows x 32 tokens per wave)
+  if (ggq_mmq_x64_tile_tokens(type, batch, k, n_rows) == 32) return 32;   // 32-token tiles: the one-tile loops (32 rows x 32 tokens per wave)
   const int64_t tt = (batch + 63) / 64;
   const int64_t u64 = ((n_rows + 63) / 64) * tt, u96 = ((n_rows + 95) / 96) * tt;
   if (u64 < 160) return 32;
   return k >= 4 * 256 && u64 > 256 && u96 <= 256 ? 96 : 64;
+}
+// tokens per wave tile: 32 (the one-tile loops: 32 rows x 32 tokens per wave) up to 32 tokens, and at 33 - 64 tokens while the launch then
+// still has at most 256 units (4096 rows: one workgroup of eight K-slices per CU) — there two 32-token tiles per 32 rows beat one
+// 64-token tile (profiles/r04b_x64_one_tile_b33_64.txt, op us cold: 4096 x 4096 Q4_K 13.5 -> 12.8, Q8_0 16.1 -> 15.0, Q5_K 14.7 -> 13.2, 3584 x 8192 Q8_0
+// 24.8 -> 21.9; 2048 x 4096 -3 ... -8 %); from 6144 rows on (more than 256 units) they lose 20 - 40 %.  Else 64.
+extern "C" int ggq_mmq_x64_tile_tokens(int type, int64_t batch, int64_t k, int64_t n_rows) {
+  (void)k;
+  if (!ggq_mmq_x64_type_supported(type)) return 64;
+  if (batch <= 32) return 32;
+  return batch <= 64 && ((n_rows + 31) / 32) * 2 <= 256 ? 32 : 64;
 }
 // fewest 32-row units from which the route takes the x64 kernel below 160 units of 64 rows (0: never)
 static int64_t x64_min_units32(int type) {
@@ -288,6 +298,11 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
   // Re-measured with the 96-row units and for all three formats of the kernel (profiles/r04b_x64_vs_stream_{q4_k,q8_0,q4_0}.txt, streamed /
   // x64, cold): from 168 units up Q4_K 1.15 - 1.45, Q8_0 1.43 - 1.6, Q4_0 1.37 - 1.55; at 96 - 128 units Q4_K 0.88 - 0.97, Q8_0 0.88 - 1.05
   // (ahead warm, level cold), Q4_0 0.98 - 1.13; below 96 units of 64 rows every format loses with 64-row units (0.68 - 0.95).
+  // Batch 33 - 64 on at most 4096 rows: two 32-token one-tile units per 32 rows (ggq_mmq_x64_tile_tokens), ahead of the streamed kernel
+  // and of the 64-token 32-row units from 2048 rows up for all four formats (profiles/r04b_x64_one_tile_b33_64.txt).
+  if (batch >= 33 && batch <= 64 && ggq_mmq_x64_supported(type, k, batch) && ggq_mmq_x64_tile_tokens(type, batch, k, n_rows) == 32 &&
+      (n_rows + 31) / 32 >= 64)
+    return GGQ_MMQ_ROUTE_X64;
   // Below 160 units the kernel's 32-row units (ggq_mmq_x64_unit_rows) take over from the band where they beat the streamed kernel.
   const int64_t x64_units = ((n_rows + 63) / 64) * ((batch + 63) / 64), x32_units = ((n_rows + 31) / 32) * ((batch + 63) / 64);
   if (batch >= 33 && ggq_mmq_x64_supported(type, k, batch) &&

@@ -346,12 +346,14 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
   static const char* e = GGQ_TUNING_ENV("GGQ_X64_KS");
   static const char* er = GGQ_TUNING_ENV("GGQ_X64_ROWS");
   if constexpr (X64Fmt<T>::HAS_T1) {
-    if (batch <= 32) {   // one 32-token tile: 32-row units of one MFMA tile per wave and group
-      const int64_t n_units = (n + 31) / 32;
+    static const char* et = GGQ_TUNING_ENV("GGQ_X64_TT1");   // tuning builds: the one-tile units up to this many tokens
+    if (et ? batch <= atoi(et) : ggq_mmq_x64_tile_tokens(T, batch, k, n) == 32) {   // 32-token tiles: 32-row units of one MFMA tile per wave and group
+      const int64_t n_tt = (batch + 31) / 32;
+      const int64_t n_units = ((n + 31) / 32) * n_tt;
       if (n_units > 0x7fffffffLL - 8) return GGQ_ERR_SHAPE;
       const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : (n_units <= 256 && k >= 8 * 256 ? 8 : 4);
-      return ks == 8 ? launch_x64_inst<T, DT, 8, 32, 1>(w, q8, y, batch, k, n, ldy, s, ep, 1, n_units)
-                     : launch_x64_inst<T, DT, 4, 32, 1>(w, q8, y, batch, k, n, ldy, s, ep, 1, n_units);
+      return ks == 8 ? launch_x64_inst<T, DT, 8, 32, 1>(w, q8, y, batch, k, n, ldy, s, ep, n_tt, n_units)
+                     : launch_x64_inst<T, DT, 4, 32, 1>(w, q8, y, batch, k, n, ldy, s, ep, n_tt, n_units);
     }
   }
   const int64_t n_tok_tiles = (batch + 63) / 64;

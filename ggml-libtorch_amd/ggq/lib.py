@@ -45,6 +45,7 @@ HIP_SYMBOLS = {
     "ggq_mmq_x64_supported": (c_int, [c_int, c_int64, c_int64]),
     "ggq_mmq_x64_k_slices": (c_int, [c_int64, c_int64, c_int64]),
     "ggq_mmq_x64_unit_rows": (c_int, [c_int, c_int64, c_int64, c_int64]),
+    "ggq_mmq_x64_tile_tokens": (c_int, [c_int, c_int64, c_int64, c_int64]),
     "ggq_quantize_q8_1_x64": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "ggq_mul_mat_q_x64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "ggq_quantize_q8_1_t16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -66,6 +67,7 @@ CPU_SYMBOLS = {
     "ggq_mmq_x64_supported": (c_int, [c_int, c_int64, c_int64]),
     "ggq_mmq_x64_k_slices": (c_int, [c_int64, c_int64, c_int64]),
     "ggq_mmq_x64_unit_rows": (c_int, [c_int, c_int64, c_int64, c_int64]),
+    "ggq_mmq_x64_tile_tokens": (c_int, [c_int, c_int64, c_int64, c_int64]),
     "ggq_cpu_dequantize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int]),
     "ggq_cpu_dequantize_f32_ex": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int]),
     "ggq_cpu_simd_name": (ctypes.c_char_p, []),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GGQ_ABI_VERSION 9   /* 9: ggq_mmq_x64_unit_rows, ggq_mul_mat_vec_q_gather, ggq_mul_mat_q_gather on the streamed route; 8: ggq_*_x64 (64 x 64 wave tiles, batches from 33 tokens), GGQ_MMQ_ROUTE_X64; 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather; 7: ggq_mmq_stream_unit_tokens */
+#define GGQ_ABI_VERSION 10   /* 10: ggq_mmq_x64_tile_tokens; 9: ggq_mmq_x64_unit_rows, ggq_mul_mat_vec_q_gather, ggq_mul_mat_q_gather on the streamed route; 8: ggq_*_x64 (64 x 64 wave tiles, batches from 33 tokens), GGQ_MMQ_ROUTE_X64; 2: IQ4_NL / IQ4_XS for dequantise + MMVQ, ggq_mmq_type_supported; 3: ggq_peer_*; 4: ggq_*_t16, ggq_mmq_route; 5: ggq_peer_scatter / _wait; 6: ggq_mul_mat_q_gather; 7: ggq_mmq_stream_unit_tokens */
 
 /* ggml type ids (HK/ggml/ggml-common.h:1128-1161) */
 enum ggq_type {
@@ -214,6 +214,9 @@ int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows);
 /* Weight rows per unit: 32 below 160 units of 64 rows (Q5_K: always), else 64, or 96 where that makes the launch one even round of at most 256
  * workgroups.  A row's bits do not depend on it (at equal K-slice count).  Host-only. */
 int ggq_mmq_x64_unit_rows(int type, int64_t batch, int64_t k, int64_t n_rows);
+/* Tokens per wave tile: 32 (one MFMA tile per wave and group, 32-row units) up to 32 tokens and, at 33 - 64 tokens, while the launch then
+ * has at most 256 units; else 64.  Host-only. */
+int ggq_mmq_x64_tile_tokens(int type, int64_t batch, int64_t k, int64_t n_rows);
 int ggq_quantize_q8_1_x64(const void* x, int x_dtype, void* q, int64_t batch, int64_t k, int type, void* stream);
 int ggq_mul_mat_q_x64(const void* w, const void* q, void* y, int type, int dtype, int64_t batch, int64_t k, int64_t n_rows,
                       int64_t ldy, int epilogue, const void* aux, void* stream);

@@ -27,7 +27,7 @@ def test_hip_library_exports_every_symbol():
     L = ggqlib.hip()  # raises if the .so is missing or a symbol is not exported
     for name in ggqlib.HIP_SYMBOLS:
         assert getattr(L, name) is not None
-    assert L.ggq_abi_version() == 9
+    assert L.ggq_abi_version() == 10
 
 
 def test_cpu_library_exports_every_symbol():

@@ -76,9 +76,11 @@ def test_mmq_routing_table():
                 # units, at least 192 (Q4_K) / 64 (Q8_0, Q4_0) units of 32 rows — for the formats the kernel serves
                 big_enough = units64(b, n) >= 160 or units32(b, n) >= {Q4_K: 192, Q5_K: 128, Q8_0: 64, Q4_0: 64}.get(int(t), 1 << 62)
                 one_tile = 17 <= b <= 32 and -(-n // 32) >= {Q4_K: 256, Q5_K: 256, Q8_0: 112, Q4_0: 112}.get(int(t), 1 << 62)   # batch 17 - 32: the one-tile loops
+                # batch 33 - 64 on 2048 ... 4096 rows: two 32-token one-tile units per 32 rows
+                one_tile2 = 33 <= b <= 64 and int(t) in (Q4_K, Q5_K, Q8_0, Q4_0) and 64 <= -(-n // 32) <= 128
                 if r == X64:
-                    assert k % 256 == 0 and ((b >= 33 and big_enough) or one_tile) and L.ggq_mmq_x64_supported(int(t), k, b) == 1
-                elif k % 256 == 0 and ((b >= 33 and big_enough) or one_tile):
+                    assert k % 256 == 0 and ((b >= 33 and big_enough) or one_tile or one_tile2) and L.ggq_mmq_x64_supported(int(t), k, b) == 1
+                elif k % 256 == 0 and ((b >= 33 and big_enough) or one_tile or one_tile2):
                     assert L.ggq_mmq_x64_supported(int(t), k, b) == 0
                 if r == T16:
                     assert k % 256 == 0 and (1 if n < 8192 else 2) <= b <= (32 if int(t) in (Q4_K, Q5_K) else 16) and L.ggq_mmq_t16_supported(int(t), k, b) == 1
@@ -93,7 +95,9 @@ def test_mmq_routing_table():
         two = X64 if n >= 8161 else T16   # (shapes here: 11008 / 28672 rows -> the x64 kernel's one-tile loops; 4096 / 3584 -> 16-token tiles)
         assert L.ggq_mmq_route(Q4_K, 32, k, n) == two and L.ggq_mmq_route(Q5_K, 17, k, n) == two
         assert L.ggq_mmq_route(Q4_K, 1, k, n) == (DOT4 if n >= 8192 else T16)
-        assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if n >= 32 * 191 + 1 else STREAM)
+        assert L.ggq_mmq_route(Q4_K, 33, k, n) == (X64 if (n >= 32 * 191 + 1 or 2048 <= n <= 4096) else STREAM)
+        assert L.ggq_mmq_x64_tile_tokens(Q4_K, 33, k, n) == (32 if n <= 4096 else 64) and L.ggq_mmq_x64_tile_tokens(Q4_K, 65, k, n) == 64 \
+            and L.ggq_mmq_x64_tile_tokens(Q4_K, 17, k, n) == 32 and L.ggq_mmq_x64_tile_tokens(Q6_K, 17, k, n) == 64
         assert L.ggq_mmq_route(Q4_K, 128, k, n) == (X64 if n >= 32 * 95 + 1 else STREAM) and L.ggq_mmq_route(Q4_K, 4096, k, n) == X64
         mid8 = LDS_TILE if n >= 8192 else STREAM   # Q8_0 17 - 64: the LDS-tile kernel only where the matrix has many rows ...
         big = lambda b: X64 if (units64(b, n) >= 160 or units32(b, n) >= 64) else None   # ... and from 33 tokens the x64 kernel (32-row units from 64 of them)

@@ -168,9 +168,13 @@ def test_mmq_x64_min_scale_range(oracle, t, batch):
     y = util.gpu_mmq_x64(w, x, t, n_rows)
     ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
     util.assert_fp_accumulate(y, ref, yabs, torch.float32, f"x64 min-term range {t.name}")
-    if batch == 20:   # the one-tile loops against the two-tile loops: the same tokens inside a 40-token launch (same units, same K-slices), bit for bit
-        x40 = torch.cat([x, _x((20, k), torch.float32, seed=5)])
-        assert torch.equal(util.gpu_mmq_x64(w, x40, t, n_rows)[:20], y), "one-tile and two-tile loops differ"
+    if batch == 20:   # the one-tile loops against the two-tile loops: the same tokens inside a 100-token launch (same units, same K-slices), bit for bit
+        assert ggqlib.hip().ggq_mmq_x64_tile_tokens(int(t), 20, k, n_rows) == 32 and ggqlib.hip().ggq_mmq_x64_tile_tokens(int(t), 100, k, n_rows) == 64
+        x100 = torch.cat([x, _x((80, k), torch.float32, seed=5)])
+        assert torch.equal(util.gpu_mmq_x64(w, x100, t, n_rows)[:20], y), "one-tile and two-tile loops differ"
+        x50 = x100[:50].contiguous()   # 33 - 64 tokens on few rows: two one-tile units per 32 rows
+        assert ggqlib.hip().ggq_mmq_x64_tile_tokens(int(t), 50, k, n_rows) == 32
+        assert torch.equal(util.gpu_mmq_x64(w, x50, t, n_rows), util.gpu_mmq_x64(w, x100, t, n_rows)[:50]), "two one-tile units and one two-tile unit differ"
 
 
 def test_mmq_x64_ldy_epilogues_unaligned_and_errors(oracle):
