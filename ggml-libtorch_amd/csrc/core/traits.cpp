@@ -267,7 +267,7 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
     // batch 16 at 28672 rows: 59 against 44 streamed — while up to 14336 rows (batch 16) / 28672 rows (batch 8: 28.4 against 36.8) it wins.
     // (The other formats' instances hold up there: Q8_0 128256 x 4096 batch 8 119 us against 143, Q5_K 80 against 103.)
     case GGQ_TYPE_Q6_K: t16_to = n_rows <= 16384 ? 16 : n_rows <= 32768 ? 8 : 0; break;
-    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;
+    case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: t16_to = 16; t16_from = n_rows < 8192 ? 2 : 5; break;   // (many rows: see many_rows_k below)
     case GGQ_TYPE_Q8_0: t16_to = 16; break;   // from batch 2 at every shape: with many rows a tie warm (13.4 against 12.9 - 13.7 us on dot4) and
                                               // 15.1 - 15.5 against 17.2 - 18.6 with the weights from HBM (profiles/r03_sweep_batch_all.txt)
     // Beyond ~12288 rows the dot4 kernel (sized for 4096 waves) stops scaling and the 5-bit formats' 16-token tiles overtake it from batch 5
@@ -282,6 +282,20 @@ extern "C" int ggq_mmq_route(int type, int64_t batch, int64_t k, int64_t n_rows)
     case GGQ_TYPE_Q3_K: t16_to = n_rows < 8192 ? 16 : 0; break;
     default: break;
   }
+  // Many rows (> 12288), batch 2 - 4, with K AND the tensor's size as inputs — the round-4 regret pass over profiles/r03_t16_many_rows.txt and
+  // r03_t16_vs_stream_b8_16.txt (tests/test_host_logic.py::test_route_regret_small_batches; op us warm / cold, dot4 | 16-token tiles):
+  //   14336 x 4096, batch 3 - 4: all four nibble formats are ahead on the 16-token tiles — Q4_0 15.5 / 18.9 | 13.8 / 14.6, Q4_1 15.0 / 16.7 | 13.2 / 13.9,
+  //   Q5_0 18.1 / 21.7 | 17.4 / 18.5, Q5_1 17.1 / 18.7 | 14.0 / 15.7; batch 2: Q4_0 14.1 / 18.4 | 13.4 / 14.6, Q5_0 16.3 / 20.4 | 16.9 / 17.9, Q4_1 / Q5_1 level.
+  //   20480 x 4096: level cold, 5 - 25 % behind warm (the launch no longer fits one resident round): dot4 stays.
+  //   Q4_0 28672 x 4096 (66 MB): 19.4 / 24.9 | 20.4 / 21.4 at batch 2, 21.6 / 25.9 | 20.8 / 21.6 at 4 — ahead with the weights from HBM, which is
+  //   where a 66 MB tensor lives; 28672 x 8192 (132 MB): 31.6 / 43.7 | 51.2 / 52.2 — far behind, and at batch 16 there 61.9 / 60.0 against 48.5 / 54.0
+  //   streamed: K = 8192 doubles every wave's request -> land -> compute chain while the rows already need several rounds.
+  if (batch <= 4 && n_rows > 12288 && ggq_block_elems(type) == 32 && type != GGQ_TYPE_Q8_0) {
+    const int64_t bytes = n_rows * ggq_row_bytes(type, k);
+    if (n_rows <= 16384 && k <= 4096) t16_from = (type == GGQ_TYPE_Q4_0 || type == GGQ_TYPE_Q5_0) ? 2 : 3;
+    else if (type == GGQ_TYPE_Q4_0 && k <= 4096 && bytes <= (96ll << 20)) t16_from = 2;
+  }
+  if (type == GGQ_TYPE_Q4_0 && batch > 8 && k > 4096 && n_rows * ggq_row_bytes(type, k) > (96ll << 20)) t16_to = 8;
   // one token through this entry point: with few rows the 16-token tiles beat the dot4 kernel there too (Q4_K 4096 x 11008 10.7 / 12.4 us
   // against 10.1 / 11.1 at batch 2; 3584 x 8192 9.3 / 10.0 against 8.5 / 9.1), with many they do not (11008 x 4096: 8.5 against 9.8)
   if (t16_to > 0 && t16_from == 2 && n_rows < 8192) t16_from = 1;
