@@ -208,6 +208,31 @@ __device__ __forceinline__ void gather_store(const GatherOut& go, int64_t idx, f
   }
 }
 
+// q = (int)roundf(x / d), bit for bit, without the IEEE division where it cannot matter.  t = x * rcp(d) is within 4.6e-5 of the correctly
+// rounded quotient Q (|Q| <= 127.00002; v_rcp_f32: 1 ulp, the product: half an ulp, Q itself: half an ulp), so whenever |t| is further
+// than 1e-3 from every k + 0.5 both round (half away from zero) to the same integer, and trunc(t + copysign(0.5, t)) is that integer.
+// Anything else — a quotient near a rounding boundary (0.2 % of the elements), NaN / inf, a scale outside 2^-100 .. 2^100 where rcp or
+// the product could leave the normal range — takes the exact division; the branch is per lane, skipped by waves without such a lane.
+// The division + roundf were ~60 % of the kernel's instructions: 4096 x 4096 tokens 26.6 -> see profiles/r04c_quantize_fast_path.txt.
+__device__ __forceinline__ void quant4(const float v[4], float amax, float d, int qi[4]) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  const uint32_t db = __builtin_bit_cast(uint32_t, d) >> 23;          // sign 0 (d >= 0): the biased exponent
+  bool slow = !(db >= 27u && db <= 227u);                              // also d == 0 (amax == 0), inf, NaN
+  float t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t[i] = v[i] * r;
+    slow |= !(fabsf(__builtin_amdgcn_fractf(fabsf(t[i])) - 0.5f) > 1e-3f);   // (NaN / inf: fract is NaN -> slow)
+  }
+  if (__builtin_expect(slow, 0)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qi[i] = amax == 0.0f ? 0 : (int)roundf(v[i] / d);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qi[i] = (int)(t[i] + copysignf(0.5f, t[i]));
+  }
+}
+
 // Experiment knobs (environment variables that force a kernel variant) exist only in -DGGQ_TUNING builds
 // (scripts/build_variant.sh); the shipped library takes no decision from the environment.
 #ifdef GGQ_TUNING

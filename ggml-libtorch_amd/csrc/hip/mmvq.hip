@@ -548,8 +548,7 @@ __global__ void __launch_bounds__(FUSED ? 1024 : 256) mmvq_kernel(const uint8_t*
       const float sum = (sm[0] + sm[2]) + (sm[1] + sm[3]);
       const float d = amax / 127;
       int qi[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) qi[i] = amax == 0.0f ? 0 : (int)roundf(v[i] / d);
+      quant4(v, amax, d, qi);   // (ggq_common.h: the exact division only for quotients near a rounding boundary)
       ((uint32_t*)xq)[ix >> 2] = (uint32_t)(qi[0] & 0xFF) | ((uint32_t)(qi[1] & 0xFF) << 8) |
                                  ((uint32_t)(qi[2] & 0xFF) << 16) | ((uint32_t)(qi[3] & 0xFF) << 24);
       int s16 = (qi[0] + qi[1]) + (qi[2] + qi[3]);   // exact: the quad's four chunks are one 16-element half
