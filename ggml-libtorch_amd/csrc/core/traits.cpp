@@ -107,6 +107,7 @@ extern "C" int ggq_mmq_x64_type_supported(int type) {
 }
 extern "C" int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows) {
   const int64_t units = ((n_rows + 63) / 64) * ((batch + 63) / 64);
+  if (units >= 2048) return 1;   // a full round of one-wave workgroups: no K-slicing (mmq_x64.hip launch_x64; 64-row units only: Q5_K's 32-row units keep 4)
   return units <= 256 && k >= 8 * 256 ? 8 : 4;
 }
 

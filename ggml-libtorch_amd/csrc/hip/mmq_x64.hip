@@ -291,8 +291,8 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
         }
     } else {
       v4i* dst = (v4i*)((uint16_t*)y + yi0);
-      dst[0] = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-      if constexpr (RPT == 16) dst[1] = v4i{(int)pk[4], (int)pk[5], (int)pk[6], (int)pk[7]};
+#pragma unroll
+      for (int c = 0; c < RPT / 8; ++c) dst[c] = v4i{(int)pk[4 * c], (int)pk[4 * c + 1], (int)pk[4 * c + 2], (int)pk[4 * c + 3]};
       for (int d = 1; d < go.n_dst; ++d)
 #pragma unroll
         for (int c = 0; c < RPT / 8; ++c) {
@@ -368,13 +368,26 @@ static int launch_x64(const void* w, const void* q8, void* y, int64_t batch, int
   }
   // at most one unit per CU: eight K-slices per unit (two waves per SIMD either way, half the K loop per wave); otherwise four, two
   // workgroups per CU (ggq_mmq_x64_k_slices, csrc/core/traits.cpp, host-testable; for 32-row units the same rule on their count)
-  const int ks = e && (e[0] == '4' || e[0] == '8') ? e[0] - '0' : (n_units <= 256 && k >= 8 * 256 ? 8 : 4);
+  // From 2048 units (one full round of the chip's 2048 wave slots — eight one-wave workgroups per CU): ONE K-slice, i.e. a wave walks the whole
+  // K of its unit and nothing is reduced across waves.  A unit's fixed part (first stage, K-slice reduction, write-back) is then paid once per
+  // 16 super-blocks instead of once per 4: 11008 x 4096 at 2048 / 4096 tokens 322 / 546 -> 274 / 492 us warm, 290 / 549 -> 257 / 484 cold;
+  // 4096 x 11008 294 / 556 -> 266 / 502; below a full round it loses (1024 units: 155 -> 203) — profiles/r04c_x64_k_slices_large_batch.txt.
+  // 64-row units (the 2 x 2-tile loop) only: with 32-row units — eight one-wave workgroups of the one-row-tile loop per CU — single 32 x 32 tiles
+  // differed from run to run (Q4_K and Q5_K alike, 4 - 11 of 11 repeats; four-wave workgroups of the same loop: 0 of 11; the 2 x 2 loop with one
+  // slice: 0 of 198 — scripts/stress_x64_repro.py, profiles/r04c_x64_k_slices_large_batch.txt): unexplained, so Q5_K keeps four slices.
+  const int ks = e && (e[0] == '4' || e[0] == '8' || e[0] == '1') ? e[0] - '0'
+                 : n_units >= 2048 && unit_rows == 64 ? 1 : (n_units <= 256 && k >= 8 * 256 ? 8 : 4);
   if (unit_rows == 32)
     return ks == 8 ? launch_x64_inst<T, DT, 8, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
+#ifdef GGQ_TUNING
+         : ks == 1 ? launch_x64_inst<T, DT, 1, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)   // (the experiment above)
+#endif
                    : launch_x64_inst<T, DT, 4, 32>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
-  if constexpr (!X64Fmt<T>::ONLY_32)
+  if constexpr (!X64Fmt<T>::ONLY_32) {
+    if (ks == 1) return launch_x64_inst<T, DT, 1, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
     return ks == 8 && k >= 8 * 256 ? launch_x64_inst<T, DT, 8, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units)
                                    : launch_x64_inst<T, DT, 4, 64>(w, q8, y, batch, k, n, ldy, s, ep, n_tok_tiles, n_units);
+  }
   return GGQ_ERR_SHAPE;
 }
 

@@ -208,8 +208,9 @@ int ggq_mul_mat_q_t16(const void* w, const void* q, void* y, int type, int dtype
  * scratch below 4 GiB (ggq_mmq_x64_supported; GGQ_ERR_SHAPE otherwise).  Epilogue arguments as ggq_mul_mat_q_pretiled_epi. */
 int ggq_mmq_x64_type_supported(int type);
 int ggq_mmq_x64_supported(int type, int64_t k, int64_t batch);
-/* K-slices (= waves) per 64 x 64 unit the x64 kernel uses for a shape: 8 while there is at most one unit per CU, else 4 (32-row units: the
- * same rule on their count; 96-row units: always 4).  Host-only. */
+/* K-slices (= waves) per 64 x 64 unit the x64 kernel uses for a shape: 8 while there is at most one unit per CU, 1 from 2048 units (a full
+ * round of one-wave workgroups: the large batches; 64-row units only), else 4 (32-row units: 8 / 4 by the same rule on their count; 96-row
+ * units: always 4).  Host-only. */
 int ggq_mmq_x64_k_slices(int64_t batch, int64_t k, int64_t n_rows);
 /* Weight rows per unit: 32 below 160 units of 64 rows (Q5_K: always), else 64, or 96 where that makes the launch one even round of at most 256
  * workgroups.  A row's bits do not depend on it (at equal K-slice count).  Host-only. */

@@ -227,6 +227,7 @@ def test_x64_launch_shape_rules():
     Q4_K, Q8_0 = 12, 8
     assert L.ggq_mmq_x64_k_slices(128, 4096, 8192) == 8 and L.ggq_mmq_x64_k_slices(128, 4096, 8193) == 4
     assert L.ggq_mmq_x64_k_slices(64, 1024, 4096) == 4                          # fewer than eight super-blocks
+    assert [L.ggq_mmq_x64_k_slices(b, 4096, 11008) for b in (512, 704, 768, 2048, 4096)] == [4, 4, 1, 1, 1]   # 172 x 12 = 2064 units: one-wave workgroups
     for b, k, n, want in ((128, 4096, 11008, 96), (128, 4096, 8192, 64), (128, 4096, 8193, 96), (128, 4096, 12288, 96), (128, 4096, 12289, 64),
                           (64, 4096, 11008, 64), (256, 4096, 4100, 96), (256, 4096, 6145, 64), (2048, 1024, 600, 96), (128, 768, 11008, 64),
                           (128, 4096, 28672, 64), (65, 1024, 8230, 96), (128, 4096, 4096, 32), (64, 4096, 8192, 32), (64, 4096, 10176, 32),

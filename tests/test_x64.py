@@ -124,6 +124,34 @@ def test_mmq_x64_32_row_units(oracle, t, dtype, batch, k, n_rows):
 
 
 @pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
+@pytest.mark.parametrize("dtype,batch,k,n_rows", [(torch.float16, 1024, 512, 8200), (torch.float32, 2100, 1280, 4100)])
+def test_mmq_x64_one_k_slice(oracle, t, dtype, batch, k, n_rows):
+    """from 2048 units of 64 rows a launch takes one-wave workgroups (one K-slice: the large batches — 129 x 16 and 65 x 33 units here; Q5_K, on
+    32-row units, keeps four-wave workgroups at the same shapes): against the oracle with ragged last units (8 / 4 rows, 52 tokens in the last token tile of the second case) and rows
+    that take the 2^-8-scaled cold pass, reproducible run to run, and the integer-exact case"""
+    L = ggqlib.hip()
+    assert L.ggq_mmq_x64_k_slices(batch, k, n_rows) == 1
+    w = synth.random_weight(t, n_rows, k, seed=batch + k + 2)
+    from ggq.synth import _F16_FIELDS
+    bs, m_off = BLOCK[t][1], _F16_FIELDS[t][1]
+    if m_off is not None and dtype != torch.float16:
+        wb = w.reshape(n_rows, -1, bs)
+        vals = np.array([6e-8, 1.0, 1023.5, 1024.5, 65504.0, -65504.0, -3.0, 0.0, -2000.0], np.float16)
+        for r in range(0, n_rows, 7):
+            for b in range(wb.shape[1]):
+                wb[r, b, m_off:m_off + 2] = vals[(r + 5 * b) % len(vals)].reshape(1).view(np.uint8)
+        w = wb.reshape(n_rows, -1)
+    x = _x((batch, k), dtype, seed=23)
+    y = util.gpu_mmq_x64(w, x, t, n_rows)
+    ref, yabs = oracle.mul_mat_q(w, x.float().cpu().numpy(), t, n_rows)
+    util.assert_fp_accumulate(y, ref, yabs, dtype, f"x64 one K-slice b={batch}")
+    for _ in range(4):
+        assert torch.equal(y, util.gpu_mmq_x64(w, x, t, n_rows)), "two launches differ"
+    if dtype == torch.float16:
+        _integer_exact(oracle, t, 4096, 256, 2100)   # 33 x 64 units
+
+
+@pytest.mark.parametrize("t", X64_TYPES, ids=lambda t: t.name)
 def test_mmq_x64_integer_exact(oracle, t):
     """power-of-two scales + integer activations: every product and partial sum is exact, so the result must equal the oracle's to
     the last bit (integer unpack, operand order and the int8 MFMA contraction)"""
