@@ -42,6 +42,10 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 struct X64Epilogue { int kind; const void* aux; GatherOut go; };
 }  // namespace ggq
 
+#ifndef GGQ_X64_TBLK
+#define GGQ_X64_TBLK 8          // token tiles per block of the blocked unit order, and the token-tile count it starts at (mmq_x64_kernel; the
+#define GGQ_X64_TBLK_FROM 16    // sweep behind both: profiles/r04c_x64_k_slices_large_batch.txt)
+#endif
 #ifndef GGQ_X64_STAMP
 #define GGQ_X64_STAMP 0   // 1: per-wave timestamps (scripts/stamps_x64.py); 0 in every shipped build
 #endif
@@ -112,7 +116,22 @@ __global__ void __launch_bounds__(UR == 96 ? 512 : 64 * KS, UR == 96 ? 1 : 2) mm
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // the units of one XCD are consecutive: a weight tile lives in one L2
   if (unit >= n_units) return;
   constexpr int UROWS = UR;
-  const int row_tile = unit / n_tok_tiles, tok_tile = unit % n_tok_tiles;
+  // unit -> (row tile, token tile).  Few token tiles: token tiles fastest (the workgroups that share a weight tile run together).  From 16 token
+  // tiles on (1024 tokens with 64-token tiles) the order is BLOCKED: eight token tiles at a time, all row tiles under them, token tile fastest
+  // inside — the units in flight on an XCD then re-read 8 x 327 KB of activation records (K = 4096) that stay in its 4 MB L2 while the weights
+  // stream past once per block, instead of streaming the whole activation scratch (21 MB at 4096 tokens) through L2 once per row tile.
+  int row_tile, tok_tile;
+  if (n_tok_tiles < GGQ_X64_TBLK_FROM) {
+    row_tile = unit / n_tok_tiles;
+    tok_tile = unit % n_tok_tiles;
+  } else {
+    constexpr int TBLK = GGQ_X64_TBLK;
+    const int nrt = n_units / n_tok_tiles;
+    const int tb = unit / (nrt * TBLK), rem = unit - tb * nrt * TBLK;
+    const int width = min(TBLK, n_tok_tiles - tb * TBLK);
+    row_tile = rem / width;
+    tok_tile = tb * TBLK + rem - row_tile * width;
+  }
   const int t0 = tok_tile * (32 * TT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
