@@ -726,8 +726,22 @@ __global__ void __launch_bounds__(64 * KS, (StreamLaunch<T, TB, KS>::WG_PER_CU *
 
   const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (unit >= n_units) return;
-  const int n0 = (unit / n_tok_tiles) * 32;
-  const int t0 = (unit % n_tok_tiles) * 32 * TB;
+  // unit -> (row tile, token tile): token tile fastest; from 16 token tiles on BLOCKED, eight token tiles at a time under all row tiles, so that
+  // the activation tiles of an XCD's units in flight stay in its L2 instead of the whole scratch streaming through once per 32-row tile
+  // (as mmq_x64.hip; profiles/r04c_x64_k_slices_large_batch.txt)
+  int row_tile, tok_tile;
+  if (n_tok_tiles < 16) {
+    row_tile = unit / n_tok_tiles;
+    tok_tile = unit % n_tok_tiles;
+  } else {
+    const int nrt = n_units / n_tok_tiles;
+    const int tb = unit / (nrt * 8), rem = unit - tb * nrt * 8;
+    const int width = min(8, n_tok_tiles - tb * 8);
+    row_tile = rem / width;
+    tok_tile = tb * 8 + rem - row_tile * width;
+  }
+  const int n0 = row_tile * 32;
+  const int t0 = tok_tile * 32 * TB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
