@@ -677,14 +677,20 @@ def main():
             detail["cpu_baseline"] = cpu_baseline()
             detail["cpu_config1_q4_0_dequant_4096x4096"] = cpu_config1()
             detail["cpu_torch_matmul_on_dequantised"] = cpu_torch_matmul()
-    elif world > 1 and not args.no_extra:
+    if rank == 0:
+        if world == 1:
+            write_extra(out, detail)
+        sys.stderr.flush()
+        print(compact_line(out, detail), flush=True)
+    if world > 1 and not args.no_extra and os.environ.get("GGQ_BENCH_STRONG", "1") == "1":
+        # AFTER the headline line is on stdout: this leg has never run across GPUs (no multi-GPU box for this build), and a fault or a
+        # stuck collective in it must not cost the scaling run its number.  Its results go to bench_extra.json and stderr only.
         ss = strong_scaling_config5(L, dev, world, rank, dist)   # collective: every rank takes part
         if rank == 0:
             detail["strong_scaling_config5"] = ss
-    if rank == 0:
+    if rank == 0 and world > 1:
         write_extra(out, detail)
         sys.stderr.flush()
-        print(compact_line(out, detail), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
