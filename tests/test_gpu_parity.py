@@ -445,6 +445,28 @@ def test_config5_shard_shape(oracle, batch):
         util.assert_fp_accumulate(y[:, sel], ref, yabs, torch.float16, f"config5 mmq b={batch}")
 
 
+@pytest.mark.parametrize("batch", [1, 8, 128])
+def test_row_sharded_equals_unsharded_config5(batch):
+    """BASELINE configs[4] at its real shape (Q4_K 28672 x 8192), the property the multi-GPU path rests on: the slab a rank computes
+    from its row shard equals the same columns of the one-GPU result.  The kernel and its K-slice count are chosen from the whole
+    (shape, batch) — 3584-row shards take eight K-slices / the GEMV K-split, the full matrix does not (include/ggq.h) — so the fp32
+    partial sums are added in a different order: equal within the canon's tolerance (1e-3 relative to the result's scale, one fp16
+    rounding), bit-for-bit only where both sides take the same route.  P = 2 and P = 8, first / middle / last shard.  No oracle."""
+    t, n_rows, k = GGMLType.Q4_K, 28672, 8192
+    w = synth.random_weight(t, n_rows, k, seed=71)
+    x = _x((batch, k), torch.float16, seed=72)
+    run = util.gpu_mmvq if batch == 1 else util.gpu_mmq
+    full = run(w, x, t, n_rows).float()
+    scale = float(full.abs().mean())
+    for world in (2, 8):
+        per = n_rows // world
+        for rank in sorted({0, world // 2, world - 1}):
+            slab = run(np.ascontiguousarray(w[rank * per:(rank + 1) * per]), x, t, per).float()
+            ref = full[:, rank * per:(rank + 1) * per]
+            err = float(((slab - ref).abs() / (ref.abs() + scale)).max())
+            assert err <= 1e-3, f"P={world} rank {rank} batch {batch}: shard differs from the unsharded result by {err:.2e}"
+
+
 @pytest.mark.parametrize("t", [GGMLType.Q4_0, GGMLType.Q4_K], ids=lambda t: t.name)
 def test_mmvq_full_size(oracle, t):
     """BASELINE config 3 shape: batch 1, K=4096, N=11008."""
